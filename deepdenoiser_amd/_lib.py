@@ -1,0 +1,126 @@
+"""ctypes binding of libdd_hip.so (the C-ABI declared in include/dd_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the compute
+layers raises.  (Build it with `python -m deepdenoiser_amd.build`.)
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdd_hip.so")
+
+DD_F32, DD_BF16 = 0, 1
+IN_RELU, OUT_RELU, ACCUM, PIXSHUF, GATHER2X2 = 1, 2, 4, 8, 16
+MAX_FEATURES, MAX_COMBINED = 32, 8
+
+# every symbol include/dd_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "dd_version", "dd_last_error", "dd_pack_weights", "dd_conv_igemm", "dd_conv_wgrad", "dd_colsum",
+    "dd_maxpool_fwd", "dd_maxpool_bwd", "dd_avgpool", "dd_prepare_feature", "dd_gather_input",
+    "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
+    "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
+    "dd_stitch", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
+)
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("cin", C.c_int),
+                ("wp", C.c_void_p), ("k_pad", C.c_int), ("n_pad", C.c_int),
+                ("bias", C.c_void_p), ("nbias", C.c_int),
+                ("res", C.c_void_p), ("ldres", C.c_int),
+                ("mask", C.c_void_p), ("ldmask", C.c_int),
+                ("y", C.c_void_p), ("ldy", C.c_int), ("n", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("taps", C.c_int), ("flags", C.c_int), ("dtype", C.c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("ldp", C.c_int), ("m", C.c_int),
+                ("q", C.c_void_p), ("ldq", C.c_int), ("n", C.c_int),
+                ("out", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("taps", C.c_int), ("flags", C.c_int), ("dtype", C.c_int), ("ksplit", C.c_int)]
+
+
+class FeatureParams(C.Structure):
+    _fields_ = [("use_log1p", C.c_int), ("mean", C.c_float), ("inv_std", C.c_float),
+                ("use_variance", C.c_int), ("variance_before", C.c_int), ("mode_neighbor", C.c_int),
+                ("relative", C.c_int), ("compress", C.c_int), ("epsilon", C.c_float)]
+
+
+class GatherEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("pixel_stride", C.c_int), ("batch_stride_pixels", C.c_int),
+                ("nch", C.c_int), ("dst_ch", C.c_int)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("n_features", C.c_int),
+                ("pred", C.c_void_p * MAX_FEATURES), ("target", C.c_void_p * MAX_FEATURES),
+                ("dpred", C.c_void_p * MAX_FEATURES),
+                ("target_ld", C.c_int * MAX_FEATURES), ("pred_ld", C.c_int * MAX_FEATURES), ("nch", C.c_int * MAX_FEATURES),
+                ("weight", C.c_float * MAX_FEATURES),
+                ("n_combined", C.c_int), ("comb", (C.c_int * 3) * MAX_COMBINED),
+                ("comb_weight", C.c_float * MAX_COMBINED),
+                ("n_image_combined", C.c_int), ("image_combined", C.c_int * MAX_COMBINED),
+                ("n_image_features", C.c_int), ("image_features", C.c_int * MAX_FEATURES),
+                ("image_weight", C.c_float), ("kind", C.c_int), ("epsilon", C.c_float)]
+
+
+class StitchEntry(C.Structure):
+    _fields_ = [("tile", C.c_int), ("crop_y0", C.c_int), ("crop_y1", C.c_int), ("crop_x0", C.c_int),
+                ("crop_x1", C.c_int), ("dst_y", C.c_int), ("dst_x", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises RuntimeError (never falls back) if it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libdd_hip.so is not built (%s missing): run `python -m deepdenoiser_amd.build`. "
+                           "There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError("libdd_hip.so lacks symbols %s: rebuild it" % missing)
+    lib.dd_version.restype = C.c_char_p
+    lib.dd_last_error.restype = C.c_char_p
+    for s in SYMBOLS[2:]:
+        getattr(lib, s).restype = C.c_int
+    vp, i, l, f = C.c_void_p, C.c_int, C.c_long, C.c_float
+    lib.dd_pack_weights.argtypes = [vp, vp, i, i, i, i, i, i, l, l, l, i, vp]
+    lib.dd_conv_igemm.argtypes = [C.POINTER(ConvArgs), vp]
+    lib.dd_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
+    lib.dd_colsum.argtypes = [vp, i, i, l, vp, i, vp]
+    lib.dd_maxpool_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
+    lib.dd_maxpool_bwd.argtypes = [vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
+    lib.dd_avgpool.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
+    lib.dd_prepare_feature.argtypes = [vp, i, vp, i, C.POINTER(FeatureParams), i, i, i, vp]
+    lib.dd_gather_input.argtypes = [vp, i, i, vp, i, i, i, i, i, i, vp]
+    lib.dd_kpcn_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
+    lib.dd_kpcn_bwd.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
+    lib.dd_compose_pack.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
+    lib.dd_compose_blend_fwd.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
+    lib.dd_compose_blend_bwd.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, i, vp, i, vp, i, i, i, i, i, i, vp]
+    lib.dd_compose_unpack_bwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, vp]
+    lib.dd_invert_std_fwd.argtypes = [vp, vp, l, i, f, f, vp]
+    lib.dd_invert_std_bwd.argtypes = [vp, vp, vp, l, i, f, f, vp]
+    lib.dd_loss_head.argtypes = [C.POINTER(LossDesc), i, i, i, vp, f, vp]
+    lib.dd_adam_step.argtypes = [vp, vp, vp, vp, l, f, f, f, f, f, vp]
+    lib.dd_stitch.argtypes = [vp, i, i, vp, i, i, i, i, vp, i, vp]
+    lib.dd_probe_tr16.argtypes = [vp, vp, vp, vp]
+    lib.dd_masked_add.argtypes = [vp, i, vp, i, vp, i, i, l, i, i, vp]
+    lib.dd_convert_channels.argtypes = [vp, i, i, vp, i, i, i, i, l, vp]
+    lib.dd_zero_stuff.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
+    lib.dd_zero_unstuff.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libdd_hip: %s (status %d)" % (load().dd_last_error().decode(), rc))

@@ -1,0 +1,150 @@
+// Shared device/host helpers for libdd_hip (gfx950 only; wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dd_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef uint16_t bf16_t;  // storage type of a bf16 element
+
+#define DD_LDS_ROW 128  // bytes of one pixel (or weight row) per K-slice in LDS
+#define DD_TILE 16      // 16x16 output pixels per workgroup
+
+// ------------------------------------------------------------------------------------------------ host-side errors
+void dd_set_error(const char* fmt, ...);
+#define DD_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      dd_set_error(__VA_ARGS__);              \
+      return DD_ERR_INVALID;                  \
+    }                                         \
+  } while (0)
+#define DD_LAUNCH_CHECK()                                                   \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      dd_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return DD_ERR_LAUNCH;                                                 \
+    }                                                                       \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ element helpers
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int PER16 = 4;  // elements per 16 bytes
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int PER16 = 8;
+  static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// relu on a 16-byte vector of T
+template <typename T> __device__ __forceinline__ uint4 relu16(uint4 v);
+template <> __device__ __forceinline__ uint4 relu16<float>(uint4 v) {
+  v.x = __float_as_uint(fmaxf(__uint_as_float(v.x), 0.f));
+  v.y = __float_as_uint(fmaxf(__uint_as_float(v.y), 0.f));
+  v.z = __float_as_uint(fmaxf(__uint_as_float(v.z), 0.f));
+  v.w = __float_as_uint(fmaxf(__uint_as_float(v.w), 0.f));
+  return v;
+}
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) { return w & ~(((w >> 15) & 0x10001u) * 0xffffu); }
+template <> __device__ __forceinline__ uint4 relu16<bf16_t>(uint4 v) {
+  v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
+  return v;
+}
+
+// 4 consecutive elements <-> float[4]
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  uint2 t;
+  t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return Elem<T>::to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = Elem<T>::from_f32(v); }
+
+// ------------------------------------------------------------------------------------------------ LDS tile image
+// One "pixel row" of an LDS tile is DD_LDS_ROW = 128 bytes = 8 slots of 16 bytes (64 bf16 / 32 f32 channels).
+// Slot s of row r is stored at physical slot s ^ (r & 7): MFMA fragment reads (16 rows x one 16-byte k-group per
+// quarter-wave) then hit 16 distinct 16-byte bank groups per ds_read_b128 service group (conflict-free for any base row).
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * DD_LDS_ROW + ((slot ^ (row & 7)) << 4); }
+
+// Geometry of the pixel tile a workgroup stages for one K-slice.
+struct TileGeom {
+  int ph, pw;      // staged pixels (rows, cols): 18x18 with halo, 16x16 without
+  int oy, ox;      // image coordinate of staged pixel (0,0) before the stride/offset mapping
+  int sy;          // 1, or 2 for the 2x2/s2 gather
+  int ay, ax;      // additive offset after the stride (the (a,b) tap of the gather)
+  int lim_y, lim_x;// validity limits of (oy+py, ox+px) (the GEMM-row pixel grid)
+  int min_y, min_x;// lower validity limits (-1 with halo => image bounds check only)
+  int hin, win;    // input image size
+};
+
+// Stage one K-slice of a pixel tile: global NHWC -> LDS [pixel][128 B], zero-filling out-of-image pixels and channels >= cin.
+template <typename T>
+__device__ __forceinline__ void stage_pixels(char* lds, const T* __restrict__ x, long img_base, int ldx, int cin, int ch0,
+                                             int nslots, const TileGeom& g, bool in_relu, int tid, int nthreads) {
+  constexpr int PER16 = Elem<T>::PER16;
+  const int total = g.ph * g.pw * 8;
+  for (int i = tid; i < total; i += nthreads) {
+    const int pix = i >> 3, slot = i & 7;
+    if (slot >= nslots) continue;
+    const int py = pix / g.pw, px = pix - py * g.pw;
+    const int ly = g.oy + py, lx = g.ox + px;
+    const int gy = ly * g.sy + g.ay, gx = lx * g.sy + g.ax;
+    const int ch = ch0 + slot * PER16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ly >= g.min_y && lx >= g.min_x && ly < g.lim_y && lx < g.lim_x && gy >= 0 && gx >= 0 && gy < g.hin && gx < g.win && ch < cin) {
+      v = *reinterpret_cast<const uint4*>(x + (img_base + (long)gy * g.win + gx) * ldx + ch);
+      if (in_relu) v = relu16<T>(v);
+    }
+    *reinterpret_cast<uint4*>(lds + lds_off(pix, slot)) = v;
+  }
+}
+
+// MFMA on one 16-byte k-group: bf16 -> one 16x16x32 MFMA; f32 -> four exact-f32 16x16x4 MFMAs (k permuted
+// consistently for both operands, which leaves the sum unchanged).
+template <typename T> __device__ __forceinline__ f32x4_t mma16(uint4 a, uint4 b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mma16<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mma16<float>(uint4 a, uint4 b, f32x4_t c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  return c;
+}
+
+static inline int dd_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,874 @@
+// HBM-bound kernels of the denoiser hot path (gfx950): weight packing, pooling, input assembly, kernel-prediction
+// filter apply, multiscale compose blend, inverse standardization, fused loss head, Adam, stitch.
+// Reference seams are cited per entry point in include/dd_hip.h.
+#include <stdarg.h>
+
+#include "dd_common.h"
+
+// ------------------------------------------------------------------------------------------------ errors / version
+static thread_local char g_err[512] = "";
+void dd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dd_last_error(void) { return g_err; }
+extern "C" const char* dd_version(void) { return "libdd_hip 0.1 (gfx950)"; }
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+static inline unsigned grid_for(long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// ------------------------------------------------------------------------------------------------ pack weights
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int taps, int n, int k, int n_pad, int k_pad,
+                            long s_tap, long s_n, long s_k, int flip) {
+  const long total = (long)taps * n_pad * k_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % k_pad);
+    const long r = i / k_pad;
+    const int nn = (int)(r % n_pad);
+    const int t = (int)(r / n_pad);
+    float v = 0.f;
+    if (nn < n && kk < k) v = src[(flip ? taps - 1 - t : t) * s_tap + nn * s_n + kk * s_k];
+    dst[i] = Elem<T>::from_f32(v);
+  }
+}
+extern "C" int dd_pack_weights(const float* src, void* dst, int dtype, int taps, int n, int k, int n_pad, int k_pad,
+                               long s_tap, long s_n, long s_k, int tap_flip, dd_stream stream) {
+  DD_REQUIRE(src && dst && taps > 0 && n > 0 && k > 0 && n_pad >= n && k_pad >= k, "dd_pack_weights: bad arguments");
+  const long total = (long)taps * n_pad * k_pad;
+  const unsigned g = min(grid_for(total), 2048u);
+  if (dtype == DD_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(g), dim3(256), 0, S(stream), src, (float*)dst, taps, n, k, n_pad, k_pad, s_tap, s_n, s_k, tap_flip);
+  else
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(g), dim3(256), 0, S(stream), src, (bf16_t*)dst, taps, n, k, n_pad, k_pad, s_tap, s_n, s_k, tap_flip);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, int ld, int c, long rows, float* __restrict__ out) {
+  __shared__ float partial[256];
+  const int cb = blockIdx.y * 64;            // 64 channels per block column
+  const int ci = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
+  const int ch = cb + ci;
+  float s = 0.f;
+  if (ch < c)
+    for (long r = (long)blockIdx.x * 4 + rl; r < rows; r += (long)gridDim.x * 4) s += ld1<T>(x + r * ld + ch);
+  partial[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && ch < c) atomicAdd(out + ch, partial[ci] + partial[64 + ci] + partial[128 + ci] + partial[192 + ci]);
+}
+extern "C" int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream) {
+  DD_REQUIRE(x && out && c > 0 && rows > 0, "dd_colsum: bad arguments");
+  dim3 g((unsigned)min((rows + 3) / 4, 1024L), (unsigned)((c + 63) / 64));
+  if (dtype == DD_F32) hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, S(stream), (const float*)x, ld, c, rows, out);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, dim3(256), 0, S(stream), (const bf16_t*)x, ld, c, rows, out);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ max pooling (TF SAME)
+__host__ __device__ inline void same_pad(int size, int k, int s, int* out, int* before) {
+  const int o = (size + s - 1) / s;
+  int total = (o - 1) * s + k - size;
+  if (total < 0) total = 0;
+  *out = o; *before = total / 2;
+}
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
+                                   int C, int B, int H, int W, int OH, int OW, int pool, int stride, int pby, int pbx) {
+  const int cg = C >> 2;
+  const long total = (long)B * OH * OW * cg;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * 4;
+  long r = i / cg;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH);
+  const int b = (int)(r / OH);
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int arg[4] = {0, 0, 0, 0};
+  for (int a = 0; a < pool; ++a)
+    for (int bb = 0; bb < pool; ++bb) {
+      const int sy = oy * stride + a - pby, sx = ox * stride + bb - pbx;
+      if (sy < 0 || sx < 0 || sy >= H || sx >= W) continue;
+      float v[4];
+      load4<T>(x + (((long)b * H + sy) * W + sx) * ldx + c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > best[e]) { best[e] = v[e]; arg[e] = a * pool + bb; }
+    }
+  const long opix = ((long)b * OH + oy) * OW + ox;
+  store4<T>(y + opix * ldy + c, best);
+  *reinterpret_cast<uchar4*>(idx + opix * C + c) = make_uchar4((uint8_t)arg[0], (uint8_t)arg[1], (uint8_t)arg[2], (uint8_t)arg[3]);
+}
+extern "C" int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
+                              int pool, int stride, int dtype, dd_stream stream) {
+  DD_REQUIRE(x && y && idx && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "dd_maxpool_fwd: C, ld must be multiples of 4");
+  int OH, OW, pby, pbx;
+  same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
+  const long total = (long)B * OH * OW * (C / 4);
+  if (dtype == DD_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)x, ldx, (float*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int lddx,
+                                   const T* __restrict__ mask, int ldmask, int C, int B, int H, int W, int OH, int OW,
+                                   int pool, int stride, int pby, int pbx, int accumulate) {
+  const int cg = C >> 2;
+  const long total = (long)B * H * W * cg;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * 4;
+  long r = i / cg;
+  const int x = (int)(r % W); r /= W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  // windows (oy, ox) that contain (y, x): oy*stride - pby <= y <= oy*stride - pby + pool - 1
+  const int oy_hi = (y + pby) / stride, ox_hi = (x + pbx) / stride;
+  for (int oy = oy_hi; oy >= 0 && oy * stride - pby + pool - 1 >= y; --oy) {
+    if (oy >= OH) continue;
+    for (int ox = ox_hi; ox >= 0 && ox * stride - pbx + pool - 1 >= x; --ox) {
+      if (ox >= OW) continue;
+      const int k = (y - (oy * stride - pby)) * pool + (x - (ox * stride - pbx));
+      const long opix = ((long)b * OH + oy) * OW + ox;
+      const uchar4 a = *reinterpret_cast<const uchar4*>(idx + opix * C + c);
+      float v[4];
+      load4<T>(dy + opix * lddy + c, v);
+      if (a.x == k) g[0] += v[0];
+      if (a.y == k) g[1] += v[1];
+      if (a.z == k) g[2] += v[2];
+      if (a.w == k) g[3] += v[3];
+    }
+  }
+  const long pix = ((long)b * H + y) * W + x;
+  if (mask) {
+    float m[4];
+    load4<T>(mask + pix * ldmask + c, m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+  }
+  T* dst = dx + pix * lddx + c;
+  if (accumulate) {
+    float o[4];
+    load4<T>(dst, o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] += o[e];
+  }
+  store4<T>(dst, g);
+}
+extern "C" int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, const void* mask, int ldmask,
+                              int C, int B, int H, int W, int pool, int stride, int accumulate, int dtype, dd_stream stream) {
+  DD_REQUIRE(dy && idx && dx && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "dd_maxpool_bwd: C, ld must be multiples of 4");
+  int OH, OW, pby, pbx;
+  same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
+  const long total = (long)B * H * W * (C / 4);
+  if (dtype == DD_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dy, lddy, idx, (float*)dx, lddx, (const float*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)dy, lddy, idx, (bf16_t*)dx, lddx, (const bf16_t*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ average pooling (fp32)
+__global__ void avgpool_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int C, int B, int H, int W, int f) {
+  const int OH = H / f, OW = W / f;
+  const long total = (long)B * OH * OW * C;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long r = i / C;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH);
+  const int b = (int)(r / OH);
+  float s = 0.f;
+  for (int a = 0; a < f; ++a)
+    for (int bb = 0; bb < f; ++bb) s += x[(((long)b * H + oy * f + a) * W + ox * f + bb) * ldx + c];
+  y[(((long)b * OH + oy) * OW + ox) * ldy + c] = s / (float)(f * f);
+}
+extern "C" int dd_avgpool(const float* x, int ldx, float* y, int ldy, int C, int B, int H, int W, int f, dd_stream stream) {
+  DD_REQUIRE(x && y && f >= 1 && H % f == 0 && W % f == 0, "dd_avgpool: H=%d W=%d must be divisible by f=%d", H, W, f);
+  const long total = (long)B * (H / f) * (W / f) * C;
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), x, ldx, y, ldy, C, B, H, W, f);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ input pipeline
+__device__ __forceinline__ int sym_index(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
+__device__ __forceinline__ float signed_log1p(float v) { return v > 0.f ? log1pf(v) : (v < 0.f ? -log1pf(-v) : 0.f); }
+__device__ __forceinline__ float standardize(float v, const dd_feature_params& fp) {
+  if (fp.use_log1p) v = signed_log1p(v);
+  return (v - fp.mean) * fp.inv_std;
+}
+
+__global__ void prepare_feature_kernel(const float* __restrict__ src, int cs, float* __restrict__ dst, int ldd,
+                                       const dd_feature_params fp, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long r = i / W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  const float* img = src + (long)b * H * W * cs;
+  float s[3];
+  for (int c = 0; c < cs; ++c) s[c] = standardize(img[((long)y * W + x) * cs + c], fp);
+  float* o = dst + i * ldd;
+  o[0] = s[0]; o[1] = cs == 3 ? s[1] : s[0]; o[2] = cs == 3 ? s[2] : s[0];
+  if (!fp.use_variance) return;
+  float var_acc = 0.f;
+  for (int c = 0; c < cs; ++c) {
+    float sum = 0.f, sumsq = 0.f;
+    int cnt = 0;
+    for (int a = -1; a <= 1; ++a)
+      for (int bb = -1; bb <= 1; ++bb) {
+        if (fp.mode_neighbor && a != 0 && bb != 0) continue;
+        float v = img[((long)sym_index(y + a, H) * W + sym_index(x + bb, W)) * cs + c];
+        if (!fp.variance_before) v = standardize(v, fp);
+        sum += v; sumsq += v * v; ++cnt;
+      }
+    const float mean = sum / cnt, meansq = sumsq / cnt;
+    float var = meansq - mean * mean;
+    if (fp.relative) var = var / fmaxf(mean * mean, fp.epsilon);
+    if (fp.compress) var_acc += var; else o[3 + c] = var;
+  }
+  if (fp.compress) o[3] = var_acc / cs;
+}
+extern "C" int dd_prepare_feature(const float* src, int cs, float* dst, int ldd, const dd_feature_params* fp, int B, int H, int W, dd_stream stream) {
+  DD_REQUIRE(src && dst && fp && (cs == 1 || cs == 3), "dd_prepare_feature: cs must be 1 or 3");
+  const int nv = fp->use_variance ? (fp->compress ? 1 : cs) : 0;
+  DD_REQUIRE(ldd >= 3 + nv, "dd_prepare_feature: ldd=%d too small for %d channels", ldd, 3 + nv);
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(prepare_feature_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), src, cs, dst, ldd, *fp, B, H, W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T>
+__global__ void gather_input_kernel(const dd_gather_entry* __restrict__ table, int n_tuples, int n_entries, T* __restrict__ dst, int ld,
+                                    int c_pad, int B, long hw) {
+  const long total = (long)n_tuples * B * hw;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long pix = i % hw;
+  const long tb = i / hw;
+  const int b = (int)(tb % B), t = (int)(tb / B);
+  T* o = dst + i * ld;
+  int used = 0;
+  for (int e = 0; e < n_entries; ++e) {
+    const dd_gather_entry en = table[t * n_entries + e];
+    if (en.nch <= 0) continue;
+    const float* s = en.src + ((long)b * en.batch_stride_pixels + pix) * en.pixel_stride;
+    for (int c = 0; c < en.nch; ++c) o[en.dst_ch + c] = Elem<T>::from_f32(s[c]);
+    used = max(used, en.dst_ch + en.nch);
+  }
+  for (int c = used; c < c_pad; ++c) o[c] = Elem<T>::from_f32(0.f);
+}
+extern "C" int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                               int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(table && dst && n_tuples > 0 && n_entries > 0 && c_pad <= ld, "dd_gather_input: bad arguments");
+  const long total = (long)n_tuples * B * H * W;
+  if (dtype == DD_F32) hipLaunchKernelGGL(gather_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (float*)dst, ld, c_pad, B, (long)H * W);
+  else hipLaunchKernelGGL(gather_input_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (bf16_t*)dst, ld, c_pad, B, (long)H * W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel prediction
+template <typename T, int KS>
+__global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
+                                float* __restrict__ out, int ldo, int B, int H, int W) {
+  constexpr int K2 = KS * KS, P = (KS - 1) / 2;
+  const long total = (long)B * H * W;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long r = i / W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  float w[K2];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < K2; ++t) { w[t] = ld1<T>(logits + i * ldl + t); mx = fmaxf(mx, w[t]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < K2; ++t) { w[t] = __expf(w[t] - mx); sum += w[t]; }
+  const float inv = 1.f / sum;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  const float* img = src + (long)b * H * W * ldsrc;
+#pragma unroll
+  for (int a = 0; a < KS; ++a) {
+    const int sy = sym_index(y + a - P, H);
+#pragma unroll
+    for (int bb = 0; bb < KS; ++bb) {
+      const int sx = sym_index(x + bb - P, W);
+      const float* s = img + ((long)sy * W + sx) * ldsrc;
+      const float wt = w[a * KS + bb] * inv;
+      o0 += wt * s[0]; o1 += wt * s[1]; o2 += wt * s[2];
+    }
+  }
+  float* o = out + i * ldo;
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+
+template <typename T, int KS>
+__global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
+                                const float* __restrict__ dout, int lddo, T* __restrict__ dlogits, int lddl, int dl_pad,
+                                int B, int H, int W) {
+  constexpr int K2 = KS * KS, P = (KS - 1) / 2;
+  const long total = (long)B * H * W;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long r = i / W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  float w[K2], dw[K2];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < K2; ++t) { w[t] = ld1<T>(logits + i * ldl + t); mx = fmaxf(mx, w[t]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < K2; ++t) { w[t] = __expf(w[t] - mx); sum += w[t]; }
+  const float inv = 1.f / sum;
+  const float g0 = dout[i * lddo], g1 = dout[i * lddo + 1], g2 = dout[i * lddo + 2];
+  const float* img = src + (long)b * H * W * ldsrc;
+  float dot = 0.f;
+#pragma unroll
+  for (int a = 0; a < KS; ++a) {
+    const int sy = sym_index(y + a - P, H);
+#pragma unroll
+    for (int bb = 0; bb < KS; ++bb) {
+      const int sx = sym_index(x + bb - P, W);
+      const float* s = img + ((long)sy * W + sx) * ldsrc;
+      const int t = a * KS + bb;
+      w[t] *= inv;
+      dw[t] = g0 * s[0] + g1 * s[1] + g2 * s[2];
+      dot += w[t] * dw[t];
+    }
+  }
+  T* o = dlogits + i * lddl;
+#pragma unroll
+  for (int t = 0; t < K2; ++t) o[t] = Elem<T>::from_f32(w[t] * (dw[t] - dot));
+  for (int t = K2; t < dl_pad; ++t) o[t] = Elem<T>::from_f32(0.f);
+}
+
+template <typename T>
+static int kpcn_dispatch(bool fwd, const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
+                         void* out, int ldo, int pad, int B, int H, int W, int ks, hipStream_t s) {
+  const long total = (long)B * H * W;
+  const dim3 g(grid_for(total, 128)), blk(128);
+#define KP_CASE(K)                                                                                                             \
+  case K:                                                                                                                      \
+    if (fwd) hipLaunchKernelGGL((kpcn_fwd_kernel<T, K>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, (float*)out, ldo, B, H, W); \
+    else hipLaunchKernelGGL((kpcn_bwd_kernel<T, K>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, dout, lddo, (T*)out, ldo, pad, B, H, W); \
+    break;
+  switch (ks) {
+    KP_CASE(3) KP_CASE(5) KP_CASE(7)
+    default: dd_set_error("kernel prediction: kernel_size %d unsupported (3, 5, 7)", ks); return DD_ERR_INVALID;
+  }
+#undef KP_CASE
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+extern "C" int dd_kpcn_fwd(const float* src, int ldsrc, const void* logits, int ldl, float* out, int ldo,
+                           int B, int H, int W, int ksize, int dtype, dd_stream stream) {
+  DD_REQUIRE(src && logits && out && ldl >= ksize * ksize, "dd_kpcn_fwd: bad arguments");
+  return dtype == DD_F32 ? kpcn_dispatch<float>(true, src, ldsrc, logits, ldl, nullptr, 0, out, ldo, 0, B, H, W, ksize, S(stream))
+                         : kpcn_dispatch<bf16_t>(true, src, ldsrc, logits, ldl, nullptr, 0, out, ldo, 0, B, H, W, ksize, S(stream));
+}
+extern "C" int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
+                           void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream) {
+  DD_REQUIRE(src && logits && dout && dlogits && ldl >= ksize * ksize && dl_pad <= lddl, "dd_kpcn_bwd: bad arguments");
+  return dtype == DD_F32 ? kpcn_dispatch<float>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream))
+                         : kpcn_dispatch<bf16_t>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ multiscale compose
+template <typename T>
+__global__ void compose_pack_kernel(const float* __restrict__ small, int lds, const float* __restrict__ fine, int ldf,
+                                    T* __restrict__ dst, int ld, int c_pad, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long r = i / W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  const float* s = small + (((long)b * (H / 2) + y / 2) * (W / 2) + x / 2) * lds;
+  const float* f = fine + i * ldf;
+  T* o = dst + i * ld;
+  o[0] = Elem<T>::from_f32(s[0]); o[1] = Elem<T>::from_f32(s[1]); o[2] = Elem<T>::from_f32(s[2]);
+  o[3] = Elem<T>::from_f32(f[0]); o[4] = Elem<T>::from_f32(f[1]); o[5] = Elem<T>::from_f32(f[2]);
+  for (int c = 6; c < c_pad; ++c) o[c] = Elem<T>::from_f32(0.f);
+}
+extern "C" int dd_compose_pack(const float* small, int lds, const float* fine, int ldf, void* dst, int ld, int c_pad,
+                               int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(small && fine && dst && H % 2 == 0 && W % 2 == 0 && c_pad >= 6 && c_pad <= ld, "dd_compose_pack: bad arguments");
+  const long total = (long)B * H * W;
+  if (dtype == DD_F32) hipLaunchKernelGGL(compose_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (float*)dst, ld, c_pad, B, H, W);
+  else hipLaunchKernelGGL(compose_pack_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (bf16_t*)dst, ld, c_pad, B, H, W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// one thread per coarse pixel (2x2 block of fine pixels)
+template <typename T>
+__global__ void compose_blend_fwd_kernel(const float* __restrict__ small, int lds, const float* __restrict__ fine, int ldf,
+                                         const T* __restrict__ wl, int ldw, float* __restrict__ out, int ldo, int B, int H, int W) {
+  const int h2 = H / 2, w2 = W / 2;
+  const long total = (long)B * h2 * w2;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int qx = (int)(i % w2);
+  const long r = i / w2;
+  const int qy = (int)(r % h2);
+  const int b = (int)(r / h2);
+  const float* s = small + i * lds;
+  long pix[4];
+  float f[4][3], low[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pix[k] = ((long)b * H + 2 * qy + (k >> 1)) * W + 2 * qx + (k & 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { f[k][c] = fine[pix[k] * ldf + c]; low[c] += f[k][c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) low[c] *= 0.25f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float w = sigmoidf(ld1<T>(wl + pix[k] * ldw));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[pix[k] * ldo + c] = f[k][c] - w * low[c] + w * s[c];
+  }
+}
+extern "C" int dd_compose_blend_fwd(const float* small, int lds, const float* fine, int ldf, const void* wl, int ldw,
+                                    float* out, int ldo, int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(small && fine && wl && out && H % 2 == 0 && W % 2 == 0, "dd_compose_blend_fwd: bad arguments");
+  const long total = (long)B * (H / 2) * (W / 2);
+  if (dtype == DD_F32) hipLaunchKernelGGL(compose_blend_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (const float*)wl, ldw, out, ldo, B, H, W);
+  else hipLaunchKernelGGL(compose_blend_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (const bf16_t*)wl, ldw, out, ldo, B, H, W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T>
+__global__ void compose_blend_bwd_kernel(const float* __restrict__ dout, int lddo, const float* __restrict__ small, int lds,
+                                         const float* __restrict__ fine, int ldf, const T* __restrict__ wl, int ldw,
+                                         float* __restrict__ dsmall, int ldds, int acc_small, float* __restrict__ dfine, int lddf,
+                                         T* __restrict__ dwl, int lddw, int dw_pad, int B, int H, int W) {
+  const int h2 = H / 2, w2 = W / 2;
+  const long total = (long)B * h2 * w2;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int qx = (int)(i % w2);
+  const long r = i / w2;
+  const int qy = (int)(r % h2);
+  const int b = (int)(r / h2);
+  const float* s = small + i * lds;
+  long pix[4];
+  float f[4][3], g[4][3], w[4], wlv[4], low[3] = {0.f, 0.f, 0.f}, tsum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pix[k] = ((long)b * H + 2 * qy + (k >> 1)) * W + 2 * qx + (k & 1);
+    wlv[k] = ld1<T>(wl + pix[k] * ldw);
+    w[k] = sigmoidf(wlv[k]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f[k][c] = fine[pix[k] * ldf + c];
+      g[k][c] = dout[pix[k] * lddo + c];
+      low[c] += f[k][c];
+      tsum[c] += w[k] * g[k][c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { low[c] *= 0.25f; dsmall[i * ldds + c] = (acc_small ? dsmall[i * ldds + c] : 0.f) + tsum[c]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float dw = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dw += g[k][c] * (s[c] - low[c]);
+      dfine[pix[k] * lddf + c] = g[k][c] - 0.25f * tsum[c];
+    }
+    const float d = wlv[k] > 0.f ? dw * w[k] * (1.f - w[k]) : 0.f;
+    T* o = dwl + pix[k] * lddw;
+    o[0] = Elem<T>::from_f32(d);
+    for (int c = 1; c < dw_pad; ++c) o[c] = Elem<T>::from_f32(0.f);
+  }
+}
+extern "C" int dd_compose_blend_bwd(const float* dout, int lddo, const float* small, int lds, const float* fine, int ldf,
+                                    const void* wl, int ldw, float* dsmall, int ldds, int accumulate_small, float* dfine, int lddf,
+                                    void* dwl, int lddw, int dw_pad, int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(dout && small && fine && wl && dsmall && dfine && dwl && H % 2 == 0 && W % 2 == 0 && dw_pad <= lddw, "dd_compose_blend_bwd: bad arguments");
+  const long total = (long)B * (H / 2) * (W / 2);
+  if (dtype == DD_F32) hipLaunchKernelGGL(compose_blend_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), dout, lddo, small, lds, fine, ldf, (const float*)wl, ldw, dsmall, ldds, accumulate_small, dfine, lddf, (float*)dwl, lddw, dw_pad, B, H, W);
+  else hipLaunchKernelGGL(compose_blend_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), dout, lddo, small, lds, fine, ldf, (const bf16_t*)wl, ldw, dsmall, ldds, accumulate_small, dfine, lddf, (bf16_t*)dwl, lddw, dw_pad, B, H, W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T>
+__global__ void compose_unpack_bwd_kernel(const T* __restrict__ dnet, int ld, float* __restrict__ dsmall, int ldds,
+                                          float* __restrict__ dfine, int lddf, int B, int H, int W) {
+  const int h2 = H / 2, w2 = W / 2;
+  const long total = (long)B * h2 * w2;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int qx = (int)(i % w2);
+  const long r = i / w2;
+  const int qy = (int)(r % h2);
+  const int b = (int)(r / h2);
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long pix = ((long)b * H + 2 * qy + (k >> 1)) * W + 2 * qx + (k & 1);
+    const T* d = dnet + pix * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      acc[c] += ld1<T>(d + c);
+      dfine[pix * lddf + c] += ld1<T>(d + 3 + c);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dsmall[i * ldds + c] += acc[c];
+}
+extern "C" int dd_compose_unpack_bwd(const void* dnet, int ld, float* dsmall, int ldds, float* dfine, int lddf,
+                                     int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(dnet && dsmall && dfine && H % 2 == 0 && W % 2 == 0 && ld >= 6, "dd_compose_unpack_bwd: bad arguments");
+  const long total = (long)B * (H / 2) * (W / 2);
+  if (dtype == DD_F32) hipLaunchKernelGGL(compose_unpack_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dnet, ld, dsmall, ldds, dfine, lddf, B, H, W);
+  else hipLaunchKernelGGL(compose_unpack_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)dnet, ld, dsmall, ldds, dfine, lddf, B, H, W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ inverse standardization
+__global__ void invert_std_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int use_log1p, float mean, float std) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float z = x[i] * std + mean;
+  if (use_log1p) z = z > 0.f ? expm1f(z) : (z < 0.f ? -expm1f(-z) : 0.f);
+  y[i] = z;
+}
+__global__ void invert_std_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n,
+                                      int use_log1p, float mean, float std) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float z = x[i] * std + mean;
+  float d = std;
+  if (use_log1p) d *= (z != 0.f) ? expf(fabsf(z)) : 0.f;  // d/dz sign(z)*expm1(|z|) = sign(z)^2 * exp(|z|)  (tf.sign(0) = 0)
+  dx[i] = dy[i] * d;
+}
+extern "C" int dd_invert_std_fwd(const float* x, float* y, long n, int use_log1p, float mean, float std, dd_stream stream) {
+  DD_REQUIRE(x && y && n > 0, "dd_invert_std_fwd: bad arguments");
+  hipLaunchKernelGGL(invert_std_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), x, y, n, use_log1p, mean, std);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+extern "C" int dd_invert_std_bwd(const float* x, const float* dy, float* dx, long n, int use_log1p, float mean, float std, dd_stream stream) {
+  DD_REQUIRE(x && dy && dx && n > 0, "dd_invert_std_bwd: bad arguments");
+  hipLaunchKernelGGL(invert_std_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), x, dy, dx, n, use_log1p, mean, std);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ loss head
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+// loss term and its derivative with respect to the prediction
+__device__ __forceinline__ void loss_term(int kind, float eps, float p, float t, float* l, float* dl) {
+  const float d = p - t;
+  switch (kind) {
+    case 1: *l = d; *dl = 1.f; break;
+    case 2: *l = fabsf(d); *dl = sgn(d); break;
+    case 3: { const float a = fabsf(d); if (a < 1.f) { *l = 0.5f * a * a; *dl = d; } else { *l = a - 0.5f; *dl = sgn(d); } break; }
+    case 4: *l = d * d; *dl = 2.f * d; break;
+    default: {
+      const float a = fabsf(d), den = fabsf(p) + fabsf(t) + eps;
+      *l = a / den;
+      *dl = sgn(d) / den - a * sgn(p) / (den * den);
+    }
+  }
+}
+
+__global__ void loss_head_kernel(const dd_loss_desc d, long npix, float inv_count, float grad_scale, float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  float loss = 0.f;
+  if (i < npix) {
+    for (int f = 0; f < d.n_features; ++f) {
+      const int nch = d.nch[f];
+      const float wgt = d.weight[f] * inv_count;
+      float* dp = d.dpred[f] + i * 3;
+      for (int c = 0; c < 3; ++c) {
+        float g = 0.f;
+        if (c < nch && wgt != 0.f) {
+          float l, dl;
+          loss_term(d.kind, d.epsilon, d.pred[f][i * d.pred_ld[f] + c], d.target[f][i * d.target_ld[f] + c], &l, &dl);
+          loss += wgt * l;
+          g = wgt * dl * grad_scale;
+        }
+        dp[c] = g;
+      }
+    }
+    if (d.n_combined > 0 || d.n_image_features > 0) {
+      float dimg[3] = {0.f, 0.f, 0.f};
+      const bool use_image = d.image_weight != 0.f && (d.n_image_combined > 0 || d.n_image_features > 0);
+      if (use_image) {
+        float ip[3] = {0.f, 0.f, 0.f}, it[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < d.n_image_combined; ++j) {
+          const int k = d.image_combined[j];
+          const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
+          for (int c = 0; c < 3; ++c) {
+            ip[c] += d.pred[fc][i * d.pred_ld[fc] + c] * (d.pred[fd][i * d.pred_ld[fd] + c] + d.pred[fi][i * d.pred_ld[fi] + c]);
+            it[c] += d.target[fc][i * d.target_ld[fc] + c] * (d.target[fd][i * d.target_ld[fd] + c] + d.target[fi][i * d.target_ld[fi] + c]);
+          }
+        }
+        for (int j = 0; j < d.n_image_features; ++j) {
+          const int f = d.image_features[j];
+          for (int c = 0; c < 3; ++c) { ip[c] += d.pred[f][i * d.pred_ld[f] + c]; it[c] += d.target[f][i * d.target_ld[f] + c]; }
+        }
+        const float wgt = d.image_weight * inv_count;
+        for (int c = 0; c < 3; ++c) {
+          float l, dl;
+          loss_term(d.kind, d.epsilon, ip[c], it[c], &l, &dl);
+          loss += wgt * l;
+          dimg[c] = wgt * dl * grad_scale;
+        }
+        for (int j = 0; j < d.n_image_features; ++j) {
+          float* dp = d.dpred[d.image_features[j]] + i * 3;
+          for (int c = 0; c < 3; ++c) dp[c] += dimg[c];
+        }
+      }
+      for (int k = 0; k < d.n_combined; ++k) {
+        const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
+        bool in_image = false;
+        for (int j = 0; j < d.n_image_combined; ++j) in_image |= (d.image_combined[j] == k);
+        const float wgt = d.comb_weight[k] * inv_count;
+        for (int c = 0; c < 3; ++c) {
+          const float pc = d.pred[fc][i * d.pred_ld[fc] + c], pd = d.pred[fd][i * d.pred_ld[fd] + c], pi = d.pred[fi][i * d.pred_ld[fi] + c];
+          float g = (use_image && in_image) ? dimg[c] : 0.f;
+          if (wgt != 0.f) {
+            const float tc = d.target[fc][i * d.target_ld[fc] + c], td = d.target[fd][i * d.target_ld[fd] + c], ti = d.target[fi][i * d.target_ld[fi] + c];
+            float l, dl;
+            loss_term(d.kind, d.epsilon, pc * (pd + pi), tc * (td + ti), &l, &dl);
+            loss += wgt * l;
+            g += wgt * dl * grad_scale;
+          }
+          d.dpred[fc][i * 3 + c] += g * (pd + pi);
+          d.dpred[fd][i * 3 + c] += g * pc;
+          d.dpred[fi][i * 3 + c] += g * pc;
+        }
+      }
+    }
+  }
+  red[threadIdx.x] = loss;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss_out, red[0]);
+}
+extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float* loss_out, float grad_scale, dd_stream stream) {
+  DD_REQUIRE(desc && loss_out && desc->n_features > 0 && desc->n_features <= DD_MAX_FEATURES && desc->n_combined <= DD_MAX_COMBINED,
+             "dd_loss_head: bad descriptor");
+  DD_REQUIRE(desc->kind >= 1 && desc->kind <= 5, "dd_loss_head: unknown loss kind %d", desc->kind);
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(loss_head_kernel, dim3(grid_for(npix)), dim3(256), 0, S(stream), *desc, npix, 1.f / (float)npix, grad_scale, loss_out);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam (TF form)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr_t, float b1, float b2, float eps, float gs) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+extern "C" int dd_adam_step(float* params, const float* grads, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                            float eps, float grad_scale, dd_stream stream) {
+  DD_REQUIRE(params && grads && m && v && n > 0, "dd_adam_step: bad arguments");
+  hipLaunchKernelGGL(adam_kernel, dim3(min(grid_for(n), 2048u)), dim3(256), 0, S(stream), params, grads, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stitch
+__global__ void stitch_kernel(const float* __restrict__ tiles, int ts, int ldt, float* __restrict__ frame, int fh, int fw, int ldf, int C,
+                              const dd_stitch_entry* __restrict__ table) {
+  const dd_stitch_entry e = table[blockIdx.x];
+  const int ch = e.crop_y1 - e.crop_y0, cw = e.crop_x1 - e.crop_x0;
+  const long total = (long)ch * cw * C;
+  for (long i = threadIdx.x; i < total; i += blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int x = (int)(r % cw), y = (int)(r / cw);
+    frame[((long)(e.dst_y + y) * fw + e.dst_x + x) * ldf + c] =
+        tiles[(((long)e.tile * ts + e.crop_y0 + y) * ts + e.crop_x0 + x) * ldt + c];
+  }
+}
+extern "C" int dd_stitch(const float* tiles, int tile_size, int ldt, float* frame, int frame_h, int frame_w, int ldf, int C,
+                         const dd_stitch_entry* table, int n_entries, dd_stream stream) {
+  DD_REQUIRE(tiles && frame && table && n_entries > 0, "dd_stitch: bad arguments");
+  hipLaunchKernelGGL(stitch_kernel, dim3(n_entries), dim3(256), 0, S(stream), tiles, tile_size, ldt, frame, frame_h, frame_w, ldf, C, table);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ executor helpers
+template <typename T>
+__global__ void masked_add_kernel(T* __restrict__ dst, int lddst, const T* __restrict__ src, int ldsrc, const T* __restrict__ mask, int ldmask,
+                                  int C, long npix, int accumulate) {
+  const int cg = C >> 2;
+  const long total = npix * cg;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * 4;
+  const long pix = i / cg;
+  float v[4];
+  load4<T>(src + pix * ldsrc + c, v);
+  if (mask) {
+    float m[4];
+    load4<T>(mask + pix * ldmask + c, m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+  }
+  T* d = dst + pix * lddst + c;
+  if (accumulate) {
+    float o[4];
+    load4<T>(d, o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += o[e];
+  }
+  store4<T>(d, v);
+}
+extern "C" int dd_masked_add(void* dst, int lddst, const void* src, int ldsrc, const void* mask, int ldmask, int C, long npix,
+                             int accumulate, int dtype, dd_stream stream) {
+  DD_REQUIRE(dst && src && C % 4 == 0 && lddst % 4 == 0 && ldsrc % 4 == 0 && (!mask || ldmask % 4 == 0), "dd_masked_add: C, ld must be multiples of 4");
+  const long total = npix * (C / 4);
+  if (dtype == DD_F32) hipLaunchKernelGGL(masked_add_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (float*)dst, lddst, (const float*)src, ldsrc, (const float*)mask, ldmask, C, npix, accumulate);
+  else hipLaunchKernelGGL(masked_add_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (bf16_t*)dst, lddst, (const bf16_t*)src, ldsrc, (const bf16_t*)mask, ldmask, C, npix, accumulate);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename TS, typename TD>
+__global__ void convert_channels_kernel(const TS* __restrict__ src, int ldsrc, TD* __restrict__ dst, int lddst, int nch, int dst_pad, long npix) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const TS* s = src + i * ldsrc;
+  TD* d = dst + i * lddst;
+  for (int c = 0; c < nch; ++c) d[c] = Elem<TD>::from_f32(Elem<TS>::to_f32(s[c]));
+  for (int c = nch; c < dst_pad; ++c) d[c] = Elem<TD>::from_f32(0.f);
+}
+extern "C" int dd_convert_channels(const void* src, int src_dtype, int ldsrc, void* dst, int dst_dtype, int lddst, int nch, int dst_pad,
+                                   long npix, dd_stream stream) {
+  DD_REQUIRE(src && dst && nch > 0 && nch <= ldsrc && dst_pad <= lddst && npix > 0, "dd_convert_channels: bad arguments");
+  const dim3 g(grid_for(npix)), b(256);
+  if (src_dtype == DD_F32 && dst_dtype == DD_F32) hipLaunchKernelGGL((convert_channels_kernel<float, float>), g, b, 0, S(stream), (const float*)src, ldsrc, (float*)dst, lddst, nch, dst_pad, npix);
+  else if (src_dtype == DD_F32) hipLaunchKernelGGL((convert_channels_kernel<float, bf16_t>), g, b, 0, S(stream), (const float*)src, ldsrc, (bf16_t*)dst, lddst, nch, dst_pad, npix);
+  else if (dst_dtype == DD_F32) hipLaunchKernelGGL((convert_channels_kernel<bf16_t, float>), g, b, 0, S(stream), (const bf16_t*)src, ldsrc, (float*)dst, lddst, nch, dst_pad, npix);
+  else hipLaunchKernelGGL((convert_channels_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)src, ldsrc, (bf16_t*)dst, lddst, nch, dst_pad, npix);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T>
+__global__ void zero_stuff_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int C, int B, int H, int W) {
+  const int cg = C >> 2;
+  const long total = (long)B * 2 * H * 2 * W * cg;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * 4;
+  long r = i / cg;
+  const int ox = (int)(r % (2 * W)); r /= 2 * W;
+  const int oy = (int)(r % (2 * H));
+  const int b = (int)(r / (2 * H));
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((oy & 1) && (ox & 1)) load4<T>(x + (((long)b * H + (oy >> 1)) * W + (ox >> 1)) * ldx + c, v);
+  store4<T>(y + (((long)b * 2 * H + oy) * 2 * W + ox) * ldy + c, v);
+}
+extern "C" int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(x && y && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "dd_zero_stuff: C, ld must be multiples of 4");
+  const long total = (long)B * 4 * H * W * (C / 4);
+  if (dtype == DD_F32) hipLaunchKernelGGL(zero_stuff_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)x, ldx, (float*)y, ldy, C, B, H, W);
+  else hipLaunchKernelGGL(zero_stuff_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, C, B, H, W);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T>
+__global__ void zero_unstuff_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, const T* __restrict__ mask, int ldmask,
+                                    int C, int B, int H, int W, int accumulate) {
+  const int cg = C >> 2;
+  const long total = (long)B * H * W * cg;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * 4;
+  long r = i / cg;
+  const int x = (int)(r % W); r /= W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  float v[4];
+  load4<T>(dy + (((long)b * 2 * H + 2 * y + 1) * 2 * W + 2 * x + 1) * lddy + c, v);
+  const long pix = ((long)b * H + y) * W + x;
+  if (mask) {
+    float m[4];
+    load4<T>(mask + pix * ldmask + c, m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+  }
+  T* d = dx + pix * lddx + c;
+  if (accumulate) {
+    float o[4];
+    load4<T>(d, o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += o[e];
+  }
+  store4<T>(d, v);
+}
+extern "C" int dd_zero_unstuff(const void* dy, int lddy, void* dx, int lddx, const void* mask, int ldmask, int C, int B, int H, int W,
+                               int accumulate, int dtype, dd_stream stream) {
+  DD_REQUIRE(dy && dx && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "dd_zero_unstuff: C, ld must be multiples of 4");
+  const long total = (long)B * H * W * (C / 4);
+  if (dtype == DD_F32) hipLaunchKernelGGL(zero_unstuff_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dy, lddy, (float*)dx, lddx, (const float*)mask, ldmask, C, B, H, W, accumulate);
+  else hipLaunchKernelGGL(zero_unstuff_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)mask, ldmask, C, B, H, W, accumulate);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ probes
+__global__ void probe_tr16_kernel(const uint16_t* __restrict__ image, const int32_t* __restrict__ addr, uint16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = image[i];
+  __syncthreads();
+  typedef __attribute__((address_space(3))) s16x4_t* lp;
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)((char*)lds + addr[threadIdx.x]));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)v[j];
+}
+extern "C" int dd_probe_tr16(const uint16_t* lds_image_4096, const int32_t* lane_byte_addr_64, uint16_t* out_64x4, dd_stream stream) {
+  DD_REQUIRE(lds_image_4096 && lane_byte_addr_64 && out_64x4, "dd_probe_tr16: null pointer");
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, S(stream), lds_image_4096, lane_byte_addr_64, out_64x4);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}

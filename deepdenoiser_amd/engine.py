@@ -1,0 +1,440 @@
+"""Static launch-graph executor over the libdd_hip C-ABI.
+
+The reference delegates execution to TensorFlow's graph runtime + autodiff (tf.estimator, reference
+TensorFlow/Training.py:1214-1232, :701-702).  The MI355X-native replacement is a *static program*: the model
+code records forward kernel launches once (shapes are static per (batch, tile) configuration); every op pushes a
+closure that emits its backward launches, so `build_backward()` produces the reverse program.  Programs are flat
+lists of bound C calls on one HIP stream -- cheap to replay and capturable into a hipGraph.
+
+Conventions (see include/dd_hip.h): NHWC; tensor = (pointer, ld); activations are stored in the graph dtype
+('f32' parity path / 'bf16' throughput path) with channel counts padded to a multiple of 8 (pad channels are
+always zero); ReLU backward is fused into the PRODUCER of a gradient (mask epilogues), so stored gradients are
+pre-activation gradients; multi-consumer tensors accumulate (first writer overwrites, later writers add).
+PyTorch provides device memory and streams only.
+"""
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+_CODE = {"f32": L.DD_F32, "bf16": L.DD_BF16}
+_ESZ = {"f32": 4, "bf16": 2}
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class DT:
+    """Device tensor handle: a channel-range view [ch0, ch0+C) of an NHWC torch buffer [B,H,W,ld]."""
+
+    zero_init_buffers = []   # gradient buffers that must be zeroed before every backward pass (registered on allocation)
+
+    def __init__(self, buf, B, H, W, C, Cp, ch0, dtype, relu=False, requires_grad=False, gstate=None):
+        self.buf, self.B, self.H, self.W, self.C, self.Cp, self.ch0, self.dtype = buf, B, H, W, C, Cp, ch0, dtype
+        self.ld = buf.shape[-1]
+        self.relu = relu                      # produced by a ReLU epilogue => incoming gradients get masked by (self > 0)
+        self.requires_grad = requires_grad
+        self.self_mask = False                # ReLU output whose consumers cannot mask (dense-concat ranges): the producer masks its own gradient in place
+        self.gstate = gstate if gstate is not None else {"buf": None, "written": False, "zero_init": False}
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.ch0 * _ESZ[self.dtype]
+
+    @property
+    def npix(self):
+        return self.B * self.H * self.W
+
+    def view(self, ch0, C, Cp=None, relu=None):
+        return DT(self.buf, self.B, self.H, self.W, C, C if Cp is None else Cp, self.ch0 + ch0, self.dtype,
+                  self.relu if relu is None else relu, self.requires_grad, self.gstate)
+
+    def grad(self):
+        """Gradient view with the same layout (allocated on first use)."""
+        if self.gstate["buf"] is None:
+            # zeros: pad channels of gradients must be zero; fully-written tensors overwrite anyway
+            self.gstate["buf"] = torch.zeros_like(self.buf)
+            if self.gstate["zero_init"]:
+                DT.zero_init_buffers.append(self.gstate["buf"])
+        return DT(self.gstate["buf"], self.B, self.H, self.W, self.C, self.Cp, self.ch0, self.dtype)
+
+    @property
+    def grad_written(self):
+        # zero_init storages (several partial-range writers) are zeroed every step and always accumulated into
+        return self.gstate["written"] or self.gstate["zero_init"]
+
+    def mark_grad_written(self):
+        self.gstate["written"] = True
+
+    def torch(self):
+        """Logical [B,H,W,C] view (for tests / outputs)."""
+        return self.buf[..., self.ch0:self.ch0 + self.C]
+
+
+class Param:
+    def __init__(self, name, shape, fan_in, fan_out, offset):
+        self.name, self.shape, self.fan_in, self.fan_out, self.offset = name, tuple(shape), fan_in, fan_out, offset
+        self.size = int(math.prod(shape))
+
+
+class ParamStore:
+    """Flat fp32 arenas (values / grads / Adam m / Adam v) in TF variable-creation order.
+    One contiguous gradient arena = zero-copy buckets for the data-parallel all-reduce and one Adam launch."""
+
+    def __init__(self):
+        self.params, self.by_name, self.total = [], {}, 0
+        self.values = self.grads = self.m = self.v = None
+
+    def get(self, name, shape, fan_in=None, fan_out=None):
+        if name in self.by_name:
+            p = self.by_name[name]
+            assert p.shape == tuple(shape), (name, p.shape, shape)
+            return p
+        assert self.values is None, "parameter store already finalized"
+        p = Param(name, shape, fan_in, fan_out, self.total)
+        self.total += round_up(p.size, 4)       # keep every parameter 16-byte aligned
+        self.params.append(p)
+        self.by_name[name] = p
+        return p
+
+    def finalize(self, device, seed=2):
+        if self.values is not None:
+            return
+        n = max(self.total, 4)
+        self.values = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=device)
+        self.m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=device)
+        gen = torch.Generator().manual_seed(seed)
+        host = torch.zeros(n, dtype=torch.float32)
+        for p in self.params:   # Glorot-uniform kernels, zero biases (TF defaults)
+            if p.fan_in is not None:
+                limit = math.sqrt(6.0 / (p.fan_in + p.fan_out))
+                host[p.offset:p.offset + p.size] = (torch.rand(p.size, generator=gen) * 2 - 1) * limit
+        self.values.copy_(host)
+
+    def value(self, p):
+        return self.values[p.offset:p.offset + p.size].view(p.shape)
+
+    def grad(self, p):
+        return self.grads[p.offset:p.offset + p.size].view(p.shape)
+
+    def value_ptr(self, p):
+        return self.values.data_ptr() + 4 * p.offset
+
+    def grad_ptr(self, p):
+        return self.grads.data_ptr() + 4 * p.offset
+
+    def load_list(self, tensors):
+        """Copy a list of tensors (creation order) into the arena -- used to share weights with the oracle."""
+        assert len(tensors) == len(self.params), (len(tensors), len(self.params))
+        for p, t in zip(self.params, tensors):
+            assert tuple(t.shape) == p.shape, (p.name, tuple(t.shape), p.shape)
+            self.value(p).copy_(t.detach().to(torch.float32))
+
+
+class ConvLayer:
+    """One conv-like layer: TF-layout fp32 master weights + MFMA-packed copies (forward / data-gradient operand)."""
+
+    def __init__(self, graph, name, k, cin, cout, kind="conv"):
+        self.g, self.name, self.k, self.cin, self.cout, self.kind = graph, name, k, cin, cout, kind
+        ps = graph.params
+        if kind == "conv":
+            self.kernel = ps.get(name + "/kernel", (k, k, cin, cout), k * k * cin, k * k * cout)
+        else:   # transpose conv: TF variable [k,k,C_out,C_in]; Glorot fans follow the variable shape
+            self.kernel = ps.get(name + "/kernel", (k, k, cout, cin), k * k * cout, k * k * cin)
+        self.bias = ps.get(name + "/bias", (cout,))
+        self._packed = {}
+
+    def packed(self, role):
+        """role 'fwd' | 'dgrad' -> (buffer, taps, n_pad, k_pad); registers the pack launch on first use."""
+        if role in self._packed:
+            return self._packed[role]
+        g, cin, cout, kind = self.g, self.cin, self.cout, self.kind
+        chunk = 64 // _ESZ[g.dtype]
+        if kind == "conv":
+            taps = self.k * self.k
+            if role == "fwd":
+                n, k, st, sn, sk, flip = cout, cin, cin * cout, 1, cout, 0
+            else:
+                n, k, st, sn, sk, flip = cin, cout, cin * cout, cout, 1, 1
+        elif kind == "convT2":
+            if role == "fwd":
+                taps, n, k, st, sn, sk, flip = 1, 4 * cout, cin, 0, cin, 1, 0
+            else:
+                taps, n, k, st, sn, sk, flip = 4, cin, cout, cout * cin, 1, cin, 0
+        else:   # convT3 == 3x3 SAME conv of the zero-stuffed input with the flipped kernel
+            taps = 9
+            if role == "fwd":
+                n, k, st, sn, sk, flip = cout, cin, cout * cin, cin, 1, 1
+            else:
+                n, k, st, sn, sk, flip = cin, cout, cout * cin, 1, cin, 0
+        n_pad, k_pad = round_up(n, 16), round_up(round_up(k, 8), chunk)
+        buf = torch.zeros(taps * n_pad * k_pad, dtype=_TORCH_DT[g.dtype], device=g.device)
+        lib, code, kernel, ps = g.lib, _CODE[g.dtype], self.kernel, g.params
+
+        def pack(stream):
+            L.check(lib.dd_pack_weights(ps.value_ptr(kernel), buf.data_ptr(), code, taps, n, k, n_pad, k_pad, st, sn, sk, flip, stream))
+        g.pack_ops.append(pack)
+        self._packed[role] = (buf, taps, n_pad, k_pad)
+        return self._packed[role]
+
+
+class Graph:
+    def __init__(self, device, dtype="f32", params=None):
+        assert dtype in _CODE
+        self.lib = L.load()
+        self.device, self.dtype, self.code = torch.device(device), dtype, _CODE[dtype]
+        self.params = params if params is not None else ParamStore()
+        self.pack_ops, self.fwd_ops, self.bwd_ops, self._tape = [], [], [], []
+        self.layers = {}
+        self.keep = []     # keeps auxiliary device buffers alive
+
+    # ------------------------------------------------------------------ tensors
+    def tensor(self, B, H, W, C, dtype=None, relu=False, requires_grad=True, ld=None, zero=True):
+        dtype = dtype or self.dtype
+        Cp = round_up(C, 8)
+        ld = ld or Cp
+        alloc = torch.zeros if zero else torch.empty
+        buf = alloc((B, H, W, ld), dtype=_TORCH_DT[dtype], device=self.device)
+        return DT(buf, B, H, W, C, Cp, 0, dtype, relu, requires_grad)
+
+    def layer(self, name, k, cin, cout, kind="conv"):
+        if name not in self.layers:
+            self.layers[name] = ConvLayer(self, name, k, cin, cout, kind)
+        lay = self.layers[name]
+        assert (lay.k, lay.cin, lay.cout, lay.kind) == (k, cin, cout, kind), name
+        return lay
+
+    # ------------------------------------------------------------------ recording helpers
+    def fwd(self, fn):
+        self.fwd_ops.append(fn)
+
+    def on_backward(self, builder):
+        """builder() is called once, in reverse recording order, and appends launches via self.bwd(...)."""
+        self._tape.append(builder)
+
+    def bwd(self, fn):
+        self.bwd_ops.append(fn)
+
+    def build_backward(self):
+        for builder in reversed(self._tape):
+            builder()
+        self._tape = []
+
+    # ------------------------------------------------------------------ conv launches
+    def _conv_call(self, x, wp, taps, n_pad, k_pad, bias, nbias, res, mask, y, B, H, W, flags):
+        a = L.ConvArgs()
+        a.x, a.ldx, a.cin = x.ptr, x.ld, x.Cp
+        a.wp, a.k_pad, a.n_pad = wp.data_ptr(), k_pad, n_pad
+        a.bias, a.nbias = bias, nbias
+        a.res, a.ldres = (res.ptr, res.ld) if res is not None else (None, 0)
+        a.mask, a.ldmask = (mask.ptr, mask.ld) if mask is not None else (None, 0)
+        a.y, a.ldy, a.n = y.ptr, y.ld, y.Cp
+        a.B, a.H, a.W, a.taps, a.flags, a.dtype = B, H, W, taps, flags, self.code
+        lib = self.lib
+        keep = (x.buf, wp, y.buf, res.buf if res is not None else None, mask.buf if mask is not None else None)
+
+        def run(stream, a=a, keep=keep):
+            L.check(lib.dd_conv_igemm(C.byref(a), stream))
+        return run
+
+    def _wgrad_call(self, p, m, q, n, out_ptr, B, H, W, taps, flags):
+        a = L.WgradArgs()
+        a.p, a.ldp, a.m = p.ptr, p.ld, m
+        a.q, a.ldq, a.n = q.ptr, q.ld, n
+        a.out = out_ptr
+        a.B, a.H, a.W, a.taps, a.flags, a.dtype, a.ksplit = B, H, W, taps, flags, self.code, 0
+        lib = self.lib
+        keep = (p.buf, q.buf)
+
+        def run(stream, a=a, keep=keep):
+            L.check(lib.dd_conv_wgrad(C.byref(a), stream))
+        return run
+
+    def _bias_grad_call(self, gy, cout, bias_param):
+        lib, code, ps = self.lib, self.code, self.params
+
+        def run(stream):
+            L.check(lib.dd_colsum(gy.ptr, gy.ld, cout, gy.npix, ps.grad_ptr(bias_param), code, stream))
+        return run
+
+    # ------------------------------------------------------------------ differentiable ops
+    def conv(self, x, layer, relu=False, in_relu=False, res=None, out=None):
+        """tf.layers.conv2d(k x k, SAME) [+ residual] [+ ReLU]; `out` may be a channel view of a concat buffer."""
+        assert layer.kind == "conv" and x.C == layer.cin, (layer.name, x.C, layer.cin)
+        y = out if out is not None else self.tensor(x.B, x.H, x.W, layer.cout, relu=relu)
+        y.relu = relu
+        assert y.C == layer.cout
+        ps = self.params
+        wp, taps, n_pad, k_pad = layer.packed("fwd")
+        flags = (L.OUT_RELU if relu else 0) | (L.IN_RELU if in_relu else 0)
+        self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, res, None, y,
+                                                     x.B, x.H, x.W, flags)))
+
+        def backward():
+            if not y.grad_written:
+                return
+            gy = y.grad()
+            self._self_mask(y, gy)
+            wflags = L.IN_RELU if in_relu else 0
+            self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags)))
+            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias)))
+            if x.requires_grad:
+                wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
+                gx = x.grad()
+                mask = x if (x.relu or in_relu) else None
+                dflags = L.ACCUM if x.grad_written else 0
+                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, mask, gx, x.B, x.H, x.W, dflags)))
+                x.mark_grad_written()
+            if res is not None and res.requires_grad:
+                self._masked_add_bwd(res, gy)
+        self.on_backward(backward)
+        return y
+
+    def _self_mask(self, y, gy):
+        if not y.self_mask:
+            return
+        lib, code = self.lib, self.code
+
+        def run(stream):
+            L.check(lib.dd_masked_add(gy.ptr, gy.ld, gy.ptr, gy.ld, y.ptr, y.ld, y.Cp, y.npix, 0, code, stream))
+        self.bwd(run)
+
+    def _masked_add_bwd(self, dst_tensor, g_src):
+        """dst_tensor.grad (+)= g_src * (dst_tensor > 0 if it is a ReLU output)."""
+        gd = dst_tensor.grad()
+        acc = 1 if dst_tensor.grad_written else 0
+        mask = dst_tensor if dst_tensor.relu else None
+        lib, code = self.lib, self.code
+
+        def run(stream):
+            L.check(lib.dd_masked_add(gd.ptr, gd.ld, g_src.ptr, g_src.ld, mask.ptr if mask is not None else None,
+                                      mask.ld if mask is not None else 0, dst_tensor.Cp, dst_tensor.npix, acc, code, stream))
+        self.bwd(run)
+        dst_tensor.mark_grad_written()
+
+    def conv_transpose2(self, x, layer, out=None, relu=True):
+        """tf.layers.conv2d_transpose(2x2, strides 2) + ReLU (UNet.py:54-59)."""
+        assert layer.kind == "convT2" and x.C == layer.cin and layer.cout % 8 == 0
+        y = out if out is not None else self.tensor(x.B, 2 * x.H, 2 * x.W, layer.cout, relu=relu)
+        y.relu = relu
+        ps = self.params
+        wp, taps, n_pad, k_pad = layer.packed("fwd")
+        flags = L.PIXSHUF | (L.OUT_RELU if relu else 0)
+        yv = DT(y.buf, y.B, y.H, y.W, 4 * layer.cout, 4 * layer.cout, y.ch0, y.dtype)   # n = (a,b,co)
+        self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, yv,
+                                                     x.B, x.H, x.W, flags)))
+
+        def backward():
+            if not y.grad_written:
+                return
+            gy = y.grad()
+            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, x, layer.cin, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, 4, L.GATHER2X2)))
+            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias)))
+            if x.requires_grad:
+                wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
+                gx = x.grad()
+                mask = x if x.relu else None
+                dflags = L.GATHER2X2 | (L.ACCUM if x.grad_written else 0)
+                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, mask, gx, x.B, x.H, x.W, dflags)))
+                x.mark_grad_written()
+        self.on_backward(backward)
+        return y
+
+    def conv_transpose3(self, x, layer, out=None, relu=True):
+        """tf.layers.conv2d_transpose(3x3, strides 2, SAME) + ReLU (Tiramisu.py:60-65) as a 3x3 SAME conv of the
+        zero-stuffed input (x[i,j] placed at (2i+1, 2j+1)) with the flipped kernel (o = 2i + a)."""
+        assert layer.kind == "convT3" and x.C == layer.cin
+        z = self.tensor(x.B, 2 * x.H, 2 * x.W, x.C, requires_grad=x.requires_grad)
+        lib, code = self.lib, self.code
+
+        def stuff(stream):
+            L.check(lib.dd_zero_stuff(x.ptr, x.ld, z.ptr, z.ld, x.Cp, x.B, x.H, x.W, code, stream))
+        self.fwd(stuff)
+        y = out if out is not None else self.tensor(x.B, 2 * x.H, 2 * x.W, layer.cout, relu=relu)
+        y.relu = relu
+        ps = self.params
+        wp, taps, n_pad, k_pad = layer.packed("fwd")
+        self.fwd(self._defer(lambda: self._conv_call(z, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, y,
+                                                     z.B, z.H, z.W, L.OUT_RELU if relu else 0)))
+
+        def backward():
+            if not y.grad_written:
+                return
+            gy = y.grad()
+            self._self_mask(y, gy)
+            # out[t][co][ci] = sum_p gy[p (+) t][co] * z[p][ci] == dKernel in TF layout [kh,kw,C_out,C_in]
+            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, z, layer.cin, ps.grad_ptr(layer.kernel), z.B, z.H, z.W, 9, 0)))
+            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias)))
+            if x.requires_grad:
+                wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
+                gz = z.grad()
+                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, None, gz, z.B, z.H, z.W, 0)))
+                gx = x.grad()
+                mask = x if x.relu else None
+                acc = 1 if x.grad_written else 0
+
+                def unstuff(stream):
+                    L.check(lib.dd_zero_unstuff(gz.ptr, gz.ld, gx.ptr, gx.ld, mask.ptr if mask is not None else None,
+                                                mask.ld if mask is not None else 0, x.Cp, x.B, x.H, x.W, acc, code, stream))
+                self.bwd(unstuff)
+                x.mark_grad_written()
+        self.on_backward(backward)
+        return y
+
+    def maxpool(self, x, pool, stride, out=None):
+        """tf.layers.max_pooling2d(padding='same') (UNet.py:42-44, Tiramisu.py:55-57)."""
+        OH, OW = -(-x.H // stride), -(-x.W // stride)
+        y = out if out is not None else self.tensor(x.B, OH, OW, x.C, requires_grad=x.requires_grad)
+        assert (y.H, y.W, y.C) == (OH, OW, x.C)
+        idx = torch.zeros((x.B, OH, OW, x.Cp), dtype=torch.uint8, device=self.device)
+        lib, code = self.lib, self.code
+
+        def run(stream):
+            L.check(lib.dd_maxpool_fwd(x.ptr, x.ld, y.ptr, y.ld, idx.data_ptr(), x.Cp, x.B, x.H, x.W, pool, stride, code, stream))
+        self.fwd(run)
+
+        def backward():
+            if not (y.grad_written and x.requires_grad):
+                return
+            gy, gx = y.grad(), x.grad()
+            mask = x if x.relu else None
+            acc = 1 if x.grad_written else 0
+
+            def runb(stream):
+                L.check(lib.dd_maxpool_bwd(gy.ptr, gy.ld, idx.data_ptr(), gx.ptr, gx.ld, mask.ptr if mask is not None else None,
+                                           mask.ld if mask is not None else 0, x.Cp, x.B, x.H, x.W, pool, stride, acc, code, stream))
+            self.bwd(runb)
+            x.mark_grad_written()
+        self.on_backward(backward)
+        return y
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _defer(make):
+        """Bind a launch lazily: parameter pointers exist only after ParamStore.finalize()."""
+        cell = []
+
+        def run(stream):
+            if not cell:
+                cell.append(make())
+            cell[0](stream)
+        return run
+
+    def finalize(self, seed=2):
+        self.params.finalize(self.device, seed)
+
+    @staticmethod
+    def stream_ptr():
+        return torch.cuda.current_stream().cuda_stream
+
+    def run(self, ops, stream=None):
+        s = self.stream_ptr() if stream is None else stream
+        for op in ops:
+            op(s)

@@ -1,0 +1,199 @@
+/*
+ * dd_hip.h -- C ABI of libdd_hip.so: hand-written CDNA4 (gfx950) HIP kernels for the conv hot
+ * path of DeepBlender/DeepDenoiser.
+ *
+ * The reference has no FFI/plugin interface (it is pure Python on TensorFlow 1.x); its seams are
+ * Python call signatures.  Each entry point below names the reference op-level seam it replaces
+ * (file:line relative to /root/reference).  Conventions:
+ *   - caller (PyTorch host) owns every buffer; the library never allocates or frees device memory
+ *     and keeps no global state; all work is enqueued on the passed hipStream_t; no implicit sync;
+ *   - activations are NHWC; a tensor is (pointer, ld) where ld = channel stride of one pixel in
+ *     ELEMENTS (so concat buffers are written in place at a channel offset);
+ *   - master weights / gradients / optimizer state are fp32 in TensorFlow variable layout:
+ *     conv kernel HWIO [kh,kw,C_in,C_out]; transpose-conv kernel [kh,kw,C_out,C_in];
+ *   - `dtype` selects the storage type of activations and packed weights: DD_F32 (parity path,
+ *     exact-f32 MFMA) or DD_BF16 (throughput path, bf16 MFMA with fp32 accumulate);
+ *   - return 0 on success, negative dd_status otherwise; dd_last_error() gives the message of the
+ *     calling thread's last failure.  No exceptions cross the ABI.
+ */
+#ifndef DD_HIP_H
+#define DD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dd_stream; /* hipStream_t */
+
+enum dd_dtype { DD_F32 = 0, DD_BF16 = 1 };
+
+enum dd_status {
+  DD_OK = 0,
+  DD_ERR_INVALID = -1,  /* bad argument / unsupported shape */
+  DD_ERR_LAUNCH = -2    /* HIP launch error */
+};
+
+/* flags of dd_conv_igemm / dd_conv_wgrad */
+enum dd_conv_flags {
+  DD_IN_RELU = 1,       /* operand is relu(x) (pre-activation convs: Tiramisu.py:33, MultiScalePrediction.py:87) */
+  DD_OUT_RELU = 2,      /* y = relu(.) (tf.layers activation=tf.nn.relu) */
+  DD_ACCUM = 4,         /* y += result (gradient accumulation for multi-consumer tensors) */
+  DD_PIXSHUF = 8,       /* 2x2/s2 transpose-conv forward: n=(a,b,co) scattered to (2y+a,2x+b,co) */
+  DD_GATHER2X2 = 16     /* 2x2/s2 gather: tap (a,b) reads input pixel (2y+a,2x+b) (transpose-conv dgrad/wgrad) */
+};
+
+const char* dd_version(void);
+const char* dd_last_error(void);
+
+/* ---- weight packing: fp32 master (TF layout) -> MFMA operand layout [taps][n_pad][k_pad] of `dtype`.
+ * dst[t][n][k] = src[tsrc*s_tap + n*s_n + k*s_k], tsrc = tap_flip ? taps-1-t : t; zero padded. */
+int dd_pack_weights(const float* src, void* dst, int dtype, int taps, int n, int k, int n_pad, int k_pad,
+                    long s_tap, long s_n, long s_k, int tap_flip, dd_stream stream);
+
+/* ---- implicit-GEMM convolution on MFMA (forward and data-gradient of every conv-like layer).
+ * Replaces tf.layers.conv2d 3x3/1x1 SAME (UNet.py:29-31; Tiramisu.py:35-37,50-52,77-79;
+ * Architecture.py:238-243; MultiScalePrediction.py:64-66,73-75,88-90), tf.layers.conv2d_transpose
+ * 2x2/s2 (UNet.py:56-58) and, with flipped/transposed packed weights, their TF-autodiff input gradients.
+ *   y[b,p,n] = epi( sum_{t,k} in(x)[b, map_t(p), k] * wp[t][n][k] + bias[n] + res[b,p,n] )
+ * taps: 9 (3x3, pad 1), 1, or 4 with DD_GATHER2X2.  epi: optional relu, then *(mask>0), then +y if DD_ACCUM. */
+typedef struct {
+  const void* x; int ldx; int cin;     /* input [B,Hin,Win,*]; cin = valid channels (multiple of 16 bytes) */
+  const void* wp; int k_pad; int n_pad;/* packed weights [taps][n_pad][k_pad] */
+  const float* bias; int nbias;        /* fp32 bias and its length (nbias <= n), or NULL */
+  const void* res; int ldres;          /* residual added before activation, or NULL */
+  const void* mask; int ldmask;        /* y *= (mask > 0), or NULL (ReLU backward fused into the producer) */
+  void* y; int ldy; int n;             /* output channels actually stored (n <= n_pad, n % 4 == 0) */
+  int B, H, W;                         /* GEMM-row pixel grid: output grid, except DD_PIXSHUF where it is the input grid */
+  int taps; int flags; int dtype;
+} dd_conv_args;
+int dd_conv_igemm(const dd_conv_args* a, dd_stream stream);
+
+/* ---- weight gradient on MFMA: out[t][m][n] += sum_{b,p} in(P)[b,map_t(p),m] * Q[b,p,n]   (fp32 atomics)
+ * conv2d:            P = layer input x, Q = pre-activation output gradient -> out = dKernel HWIO
+ * conv2d_transpose:  P = output gradient (fine grid, DD_GATHER2X2), Q = layer input -> out = dKernel [a,b,co,ci]
+ * Replaces the TF-autodiff filter gradients behind AdamOptimizer.minimize (Training.py:701-702). */
+typedef struct {
+  const void* p; int ldp; int m;       /* P operand and its logical channel count (= out dim m) */
+  const void* q; int ldq; int n;       /* Q operand and its logical channel count (= out dim n); channels up to the next
+                                          multiple of 16 bytes must be readable and zero in both operands */
+  float* out;                          /* [taps][m][n] fp32, accumulated atomically (zero it first) */
+  int B, H, W;                         /* grid of Q (the reduction pixels) */
+  int taps; int flags; int dtype;
+  int ksplit;                          /* number of reduction splits (0 = choose) */
+} dd_wgrad_args;
+int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream);
+
+/* column sums: out[c] += sum_rows x[row*ld + c]  (bias gradients; embedding-row gradients) */
+int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream);
+
+/* ---- max pooling, TF SAME (UNet.py:42-44 3x3/s2; Tiramisu.py:55-57 2x2/s2); idx = window argmax (uint8) */
+int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
+                   int pool, int stride, int dtype, dd_stream stream);
+/* dx (+)= scatter(dy) masked by (mask>0) if mask != NULL */
+int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, const void* mask, int ldmask,
+                   int C, int B, int H, int W, int pool, int stride, int accumulate, int dtype, dd_stream stream);
+
+/* ---- f x f average pooling, stride f, fp32 (MultiScalePrediction.scale_down, MultiScalePrediction.py:11-13) */
+int dd_avgpool(const float* x, int ldx, float* y, int ldy, int C, int B, int H, int W, int f, dd_stream stream);
+
+/* ---- input pipeline (FeatureStandardization.standardize Architecture.py:39-46; FeatureEngineering.variance
+ * FeatureEngineering.py:57-70): src [B,H,W,cs] fp32 (cs in {1,3}) -> dst [B,H,W,ldd] fp32 =
+ * {3 standardized channels (1-ch sources replicated, SourceEncoder.py:49-51), local variance (1 channel, or cs if not compressed)}. */
+typedef struct {
+  int use_log1p; float mean; float inv_std;      /* standardize */
+  int use_variance; int variance_before; int mode_neighbor; int relative; int compress; float epsilon;
+} dd_feature_params;
+int dd_prepare_feature(const float* src, int cs, float* dst, int ldd, const dd_feature_params* fp, int B, int H, int W, dd_stream stream);
+
+/* channel gather/concat into the network input (SourceEncoder.prepare_neural_network_input, SourceEncoder.py:29-79,
+ * incl. the embedding broadcast of FeatureFlags.feature_flags, FeatureFlags.py:50-69).
+ * table: n_tuples x n_entries device records; dst [n_tuples*B,H,W,ld] of dtype, channels >= used ones zeroed up to c_pad. */
+typedef struct { const float* src; int pixel_stride; int batch_stride_pixels; int nch; int dst_ch; } dd_gather_entry;
+int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                    int B, int H, int W, int dtype, dd_stream stream);
+
+/* ---- kernel prediction (KernelPrediction.kernel_prediction, KernelPrediction.py:11-63): softmax over k*k logits,
+ * symmetric pad, per-pixel k x k filter of the 3-channel source. */
+int dd_kpcn_fwd(const float* src, int ldsrc, const void* logits, int ldl, float* out, int ldo,
+                int B, int H, int W, int ksize, int dtype, dd_stream stream);
+int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
+                void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream);
+
+/* ---- multiscale compose (MultiScalePrediction.compose_scales, MultiScalePrediction.py:36-54) */
+/* net input = concat(nearest_x2(small), fine), zero padded to c_pad channels */
+int dd_compose_pack(const float* small, int lds, const float* fine, int ldf, void* dst, int ld, int c_pad,
+                    int B, int H, int W, int dtype, dd_stream stream);
+/* out = fine - w*up(avg2(fine)) + w*up(small), w = sigmoid(wl)  (wl = relu'd 1-channel net output) */
+int dd_compose_blend_fwd(const float* small, int lds, const float* fine, int ldf, const void* wl, int ldw,
+                         float* out, int ldo, int B, int H, int W, int dtype, dd_stream stream);
+/* backward of the blend: dfine (overwritten), dsmall (overwritten or accumulated) and dwl (gradient at the pre-relu net output) */
+int dd_compose_blend_bwd(const float* dout, int lddo, const float* small, int lds, const float* fine, int ldf,
+                         const void* wl, int ldw, float* dsmall, int ldds, int accumulate_small, float* dfine, int lddf,
+                         void* dwl, int lddw, int dw_pad, int B, int H, int W, int dtype, dd_stream stream);
+/* backward of compose_pack: dsmall += sum_2x2 dnet[0:3]; dfine += dnet[3:6] */
+int dd_compose_unpack_bwd(const void* dnet, int ld, float* dsmall, int ldds, float* dfine, int lddf,
+                          int B, int H, int W, int dtype, dd_stream stream);
+
+/* ---- inverse standardization (Architecture.py:48-55, Utilities.py:6-7), in place capable */
+int dd_invert_std_fwd(const float* x, float* y, long n, int use_log1p, float mean, float std, dd_stream stream);
+/* dx = dy * d(invert)/dx evaluated at the standardized value x */
+int dd_invert_std_bwd(const float* x, const float* dy, float* dx, long n, int use_log1p, float mean, float std, dd_stream stream);
+
+/* ---- loss head (LossDifference.difference LossDifference.py:15-35; BaseFeatureTraining.mean/loss Training.py:126-129,
+ * 210-243; Combined*FeatureTraining.initialize Training.py:420-437,475-495): per-pixel evaluation of every feature loss,
+ * combined-feature loss (color*(direct+indirect)) and combined-image loss at one scale, fused with its own backward. */
+#define DD_MAX_FEATURES 32
+#define DD_MAX_COMBINED 8
+typedef struct {
+  int n_features;
+  const float* pred[DD_MAX_FEATURES];    /* [B,H,W,pred_ld] internal prediction (1-channel passes use channel 0) */
+  const float* target[DD_MAX_FEATURES];  /* [B,H,W,target_ld], first nch channels used */
+  float* dpred[DD_MAX_FEATURES];         /* [B,H,W,3] overwritten (all 3 channels) */
+  int target_ld[DD_MAX_FEATURES];        /* pixel stride of target */
+  int pred_ld[DD_MAX_FEATURES];          /* pixel stride of pred (3, or 4 when a source is echoed) */
+  int nch[DD_MAX_FEATURES];
+  float weight[DD_MAX_FEATURES];         /* loss weight incl. scale factor; the 1/(B*H*W) mean is applied inside */
+  int n_combined;
+  int comb[DD_MAX_COMBINED][3];          /* feature indices of color, direct, indirect */
+  float comb_weight[DD_MAX_COMBINED];
+  int n_image_combined; int image_combined[DD_MAX_COMBINED];   /* indices into comb[] */
+  int n_image_features; int image_features[DD_MAX_FEATURES];   /* indices into features */
+  float image_weight;
+  int kind;                              /* 1 DIFFERENCE, 2 ABSOLUTE, 3 SMOOTH_ABSOLUTE, 4 SQUARED, 5 SMAPE */
+  float epsilon;
+} dd_loss_desc;
+/* loss_out[0] += total weighted loss of this scale; dpred written. desc is a HOST struct (copied by value). */
+int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float* loss_out, float grad_scale, dd_stream stream);
+
+/* ---- Adam, TensorFlow formulation (tf.train.AdamOptimizer, Training.py:701-702), flat arenas */
+int dd_adam_step(float* params, const float* grads, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                 float eps, float grad_scale, dd_stream stream);
+
+/* ---- inference stitch (Prediction.py:384-441): copy crop windows of row-major tiles into the frame */
+typedef struct { int tile; int crop_y0, crop_y1, crop_x0, crop_x1; int dst_y, dst_x; } dd_stitch_entry;
+int dd_stitch(const float* tiles, int tile_size, int ldt, float* frame, int frame_h, int frame_w, int ldf, int C,
+              const dd_stitch_entry* table, int n_entries, dd_stream stream);
+
+/* ---- small helpers of the graph executor */
+/* dst (+)= src * (mask > 0)   (identity/residual gradient paths into ReLU outputs); mask may be NULL */
+int dd_masked_add(void* dst, int lddst, const void* src, int ldsrc, const void* mask, int ldmask, int C, long npix,
+                  int accumulate, int dtype, dd_stream stream);
+/* dst[pix][0:nch] = convert(src[pix][0:nch]); dst[pix][nch:dst_pad] = 0   (dtype codes per tensor; fp32 <-> graph dtype) */
+int dd_convert_channels(const void* src, int src_dtype, int ldsrc, void* dst, int dst_dtype, int lddst, int nch, int dst_pad,
+                        long npix, dd_stream stream);
+/* 3x3/s2 transpose conv (Tiramisu.py:62-64) = 3x3 SAME conv of the zero-stuffed input with the flipped kernel:
+ * y[B,2H,2W,C] = 0 except y[2i+1,2j+1] = x[i,j]; and its adjoint dx[i,j] (+)= dy[2i+1,2j+1] * (mask>0). */
+int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, int B, int H, int W, int dtype, dd_stream stream);
+int dd_zero_unstuff(const void* dy, int lddy, void* dx, int lddx, const void* mask, int ldmask, int C, int B, int H, int W,
+                    int accumulate, int dtype, dd_stream stream);
+
+/* ---- probes used by the test-suite to pin hardware fragment layouts the kernels rely on */
+int dd_probe_tr16(const uint16_t* lds_image_4096, const int32_t* lane_byte_addr_64, uint16_t* out_64x4, dd_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DD_HIP_H */

@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/dd_hip.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+from deepdenoiser_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "dd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_error_strings(lib):
+    assert b"gfx950" in lib.dd_version()
+    assert isinstance(lib.dd_last_error(), bytes)
+
+
+def test_invalid_arguments_return_status_not_exception(lib):
+    a = _lib.ConvArgs()          # all-null
+    assert lib.dd_conv_igemm(ctypes.byref(a), None) == -1
+    assert b"null" in lib.dd_last_error()
+    w = _lib.WgradArgs()
+    assert lib.dd_conv_wgrad(ctypes.byref(w), None) == -1
+    assert lib.dd_adam_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 1.0, None) == -1
+
+
+def test_struct_sizes_match_header(lib):
+    # compile a tiny C program against the header and compare sizeof() of every struct with the ctypes mirror
+    import subprocess, tempfile
+    src = r'''
+#include <stdio.h>
+#include "dd_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(dd_conv_args), sizeof(dd_wgrad_args), sizeof(dd_feature_params),
+  sizeof(dd_gather_entry), sizeof(dd_loss_desc), sizeof(dd_stitch_entry)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    mirror = [ctypes.sizeof(t) for t in (_lib.ConvArgs, _lib.WgradArgs, _lib.FeatureParams, _lib.GatherEntry, _lib.LossDesc, _lib.StitchEntry)]
+    assert sizes == mirror
