@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Headline benchmark: train tiles/s of the U-Net KPCN hot path (BASELINE.json config 2) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full training step of the hot path over one batch of synthetic render-pass tiles already resident in HBM:
+standardize+variance+assemble (32 ch) -> U-Net [64,96,128]x4 -> 1x1 x2 -> 5x5 kernel-prediction apply at 3 scales ->
+multiscale compose x2 -> inverse standardization -> multi-scale SMAPE loss -> full backward -> (RCCL gradient all-reduce
+for N>1) -> Adam.  Unit: 128x128 tile-passes per second, whole job.  bf16 storage / MFMA with fp32
+accumulate, fp32 master weights and optimizer state.  Weak scaling: per-GPU batch fixed.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel = the MFMA implicit-GEMM
+conv, timed per launch with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle -- a PyTorch-CPU restatement
+of the TensorFlow graph, TF itself is unavailable -- timed on a bounded sample of the same workload; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def synthetic_inputs(arch, B, H, W, device, seed):
+    from deepdenoiser_amd.naming import Naming
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    feats, labels = {}, {}
+    for f in arch.feature_predictions + arch.auxiliary_features:
+        v = torch.randn(B, H, W, f.number_of_channels, generator=g)
+        if f.name != "Normal":
+            v = v.abs() * torch.exp(0.5 * torch.randn(B, H, W, 1, generator=g))      # HDR-like radiance proxy
+        feats[Naming.source_feature_name(f.name, index=0)] = v.to(device)
+    for f in arch.feature_predictions:
+        labels[Naming.target_feature_name(f.name)] = torch.randn(B, H, W, f.number_of_channels, generator=g).abs().to(device)
+    return feats, labels
+
+
+def conv_flops(prog):
+    """Algorithmic FLOPs of the MFMA conv launches (forward + data-gradient) of one step, from the logical layer shapes."""
+    total = 0.0
+    for rec in prog.g.conv_records:
+        total += rec["flops"]
+    return total
+
+
+def cpu_baseline(aj, tj, H, W, budget_s=25.0):
+    """The oracle timed on the host cores: fwd + loss + bwd + Adam of the same network, bounded sample."""
+    from oracle.model import OracleArchitecture
+    from oracle import training as OT
+    from deepdenoiser_amd.naming import Naming
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    B = 1
+    o = OracleArchitecture(aj, dtype=torch.float32, seed=2)
+    g = torch.Generator().manual_seed(0)
+    feats = {Naming.source_feature_name(f.name, index=0): torch.randn(B, H, W, f.channels, generator=g).abs() for f in o.features + o.auxiliary}
+    labels = {Naming.target_feature_name(f.name): torch.randn(B, H, W, f.channels, generator=g).abs() for f in o.features}
+    state = ([], [])
+    OT.train_step(o, aj, tj, feats, labels, state, 1)       # warm-up (allocations, oneDNN primitive caches)
+    t0 = time.time()
+    n = 0
+    while True:
+        OT.train_step(o, aj, tj, feats, labels, state, n + 2)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 10:
+            break
+    dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": "%d training steps of %d tile(s) %dx%dx32ch, same network, fp32, PyTorch-CPU restatement of the TF graph "
+                      "(oracle/; TensorFlow itself is not installable)" % (n, B, H, W)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="tile-passes per GPU per step")
+    ap.add_argument("--tile", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from deepdenoiser_amd import configs
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.training import Trainer
+
+    aj, tj = configs.cfg2_unet_kpcn(), configs.bench_training()
+    arch = Architecture(aj, device=device, dtype=args.dtype, seed=2)       # identical init on every rank
+    B, H, W = args.batch, args.tile, args.tile
+    trainer = Trainer(arch, tj, B, H, W, world_size=world, use_graph=not args.no_graph)
+    feats, labels = synthetic_inputs(arch, B, H, W, device, seed=1000 + rank)    # per-rank data shard
+    trainer.program.set_inputs(feats, labels)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(trainer.program.loss_buf)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream (outside the timed region)
+    roof = None
+    if rank == 0:
+        times = trainer.program.profile_ops()           # {kernel family: (launches, total_ms, flops)}
+        fam = "conv_igemm"
+        n, ms, flops = times[fam]
+        achieved = flops / (ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (fwd+dgrad implicit GEMM)" % args.dtype, "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches_per_step": n, "avg_launch_us": 1e3 * ms / n,
+                "algorithmic_gflop_per_step": flops / 1e9,
+                "other_kernels_ms_per_step": {k: round(v[1], 3) for k, v in times.items() if k != fam}}
+    if rank == 0:
+        out = {
+            "metric": "train tiles/sec (128x128x32ch U-Net KPCN)", "value": world * B * args.steps / dt, "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: U-Net [64,96,128]x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction, "
+                                   "32-channel render-pass stack, %dx%d tiles, full training step (fwd+SMAPE loss+bwd+Adam)" % (H, W),
+                       "tiles_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "hipgraph": not args.no_graph, "final_loss": loss},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(aj, tj, H, W)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -633,14 +633,18 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, float inv_coun
         for (int j = 0; j < d.n_image_combined; ++j) {
           const int k = d.image_combined[j];
           const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
-          for (int c = 0; c < 3; ++c) {
-            ip[c] += d.pred[fc][i * d.pred_ld[fc] + c] * (d.pred[fd][i * d.pred_ld[fd] + c] + d.pred[fi][i * d.pred_ld[fi] + c]);
-            it[c] += d.target[fc][i * d.target_ld[fc] + c] * (d.target[fd][i * d.target_ld[fd] + c] + d.target[fi][i * d.target_ld[fi] + c]);
+          for (int c = 0; c < 3; ++c) {   // 1-channel passes broadcast over the 3 channels (tf.multiply broadcasting, Training.py:422-426)
+            const int cc = d.nch[fc] == 1 ? 0 : c, cd = d.nch[fd] == 1 ? 0 : c, ci = d.nch[fi] == 1 ? 0 : c;
+            ip[c] += d.pred[fc][i * d.pred_ld[fc] + cc] * (d.pred[fd][i * d.pred_ld[fd] + cd] + d.pred[fi][i * d.pred_ld[fi] + ci]);
+            it[c] += d.target[fc][i * d.target_ld[fc] + cc] * (d.target[fd][i * d.target_ld[fd] + cd] + d.target[fi][i * d.target_ld[fi] + ci]);
           }
         }
         for (int j = 0; j < d.n_image_features; ++j) {
           const int f = d.image_features[j];
-          for (int c = 0; c < 3; ++c) { ip[c] += d.pred[f][i * d.pred_ld[f] + c]; it[c] += d.target[f][i * d.target_ld[f] + c]; }
+          for (int c = 0; c < 3; ++c) {
+            const int cf = d.nch[f] == 1 ? 0 : c;
+            ip[c] += d.pred[f][i * d.pred_ld[f] + cf]; it[c] += d.target[f][i * d.target_ld[f] + cf];
+          }
         }
         const float wgt = d.image_weight * inv_count;
         for (int c = 0; c < 3; ++c) {
@@ -651,7 +655,7 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, float inv_coun
         }
         for (int j = 0; j < d.n_image_features; ++j) {
           float* dp = d.dpred[d.image_features[j]] + i * 3;
-          for (int c = 0; c < 3; ++c) dp[c] += dimg[c];
+          for (int c = 0; c < 3; ++c) dp[d.nch[d.image_features[j]] == 1 ? 0 : c] += dimg[c];
         }
       }
       for (int k = 0; k < d.n_combined; ++k) {
@@ -660,18 +664,19 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, float inv_coun
         for (int j = 0; j < d.n_image_combined; ++j) in_image |= (d.image_combined[j] == k);
         const float wgt = d.comb_weight[k] * inv_count;
         for (int c = 0; c < 3; ++c) {
-          const float pc = d.pred[fc][i * d.pred_ld[fc] + c], pd = d.pred[fd][i * d.pred_ld[fd] + c], pi = d.pred[fi][i * d.pred_ld[fi] + c];
+          const int cc = d.nch[fc] == 1 ? 0 : c, cd = d.nch[fd] == 1 ? 0 : c, ci = d.nch[fi] == 1 ? 0 : c;
+          const float pc = d.pred[fc][i * d.pred_ld[fc] + cc], pd = d.pred[fd][i * d.pred_ld[fd] + cd], pi = d.pred[fi][i * d.pred_ld[fi] + ci];
           float g = (use_image && in_image) ? dimg[c] : 0.f;
           if (wgt != 0.f) {
-            const float tc = d.target[fc][i * d.target_ld[fc] + c], td = d.target[fd][i * d.target_ld[fd] + c], ti = d.target[fi][i * d.target_ld[fi] + c];
+            const float tc = d.target[fc][i * d.target_ld[fc] + cc], td = d.target[fd][i * d.target_ld[fd] + cd], ti = d.target[fi][i * d.target_ld[fi] + ci];
             float l, dl;
             loss_term(d.kind, d.epsilon, pc * (pd + pi), tc * (td + ti), &l, &dl);
             loss += wgt * l;
             g += wgt * dl * grad_scale;
           }
-          d.dpred[fc][i * 3 + c] += g * (pd + pi);
-          d.dpred[fd][i * 3 + c] += g * pc;
-          d.dpred[fi][i * 3 + c] += g * pc;
+          d.dpred[fc][i * 3 + cc] += g * (pd + pi);
+          d.dpred[fd][i * 3 + cd] += g * pc;
+          d.dpred[fi][i * 3 + ci] += g * pc;
         }
       }
     }

@@ -194,6 +194,7 @@ class Graph:
         self.pack_ops, self.fwd_ops, self.bwd_ops, self._tape = [], [], [], []
         self.layers = {}
         self.keep = []     # keeps auxiliary device buffers alive
+        self.conv_records, self.wgrad_records = [], []
 
     # ------------------------------------------------------------------ tensors
     def tensor(self, B, H, W, C, dtype=None, relu=False, requires_grad=True, ld=None, zero=True):
@@ -212,14 +213,19 @@ class Graph:
         return lay
 
     # ------------------------------------------------------------------ recording helpers
-    def fwd(self, fn):
+    def fwd(self, fn, tag="pointwise"):
+        if not hasattr(fn, "tag"):
+            fn.tag = tag
         self.fwd_ops.append(fn)
 
     def on_backward(self, builder):
         """builder() is called once, in reverse recording order, and appends launches via self.bwd(...)."""
         self._tape.append(builder)
 
-    def bwd(self, fn):
+    def bwd(self, fn, tag="pointwise", grad_params=()):
+        if not hasattr(fn, "tag"):
+            fn.tag = tag
+        fn.grad_params = tuple(grad_params)      # parameters whose gradient this launch (partially) produces
         self.bwd_ops.append(fn)
 
     def build_backward(self):
@@ -228,7 +234,9 @@ class Graph:
         self._tape = []
 
     # ------------------------------------------------------------------ conv launches
-    def _conv_call(self, x, wp, taps, n_pad, k_pad, bias, nbias, res, mask, y, B, H, W, flags):
+    def _conv_call(self, x, wp, taps, n_pad, k_pad, bias, nbias, res, mask, y, B, H, W, flags, nk=None):
+        if nk is not None:   # algorithmic FLOPs of this launch from the LOGICAL layer shape (roofline accounting, bench.py)
+            self.conv_records.append({"flops": 2.0 * B * H * W * taps * nk[0] * nk[1], "B": B, "H": H, "W": W, "taps": taps, "n": nk[0], "k": nk[1]})
         a = L.ConvArgs()
         a.x, a.ldx, a.cin = x.ptr, x.ld, x.Cp
         a.wp, a.k_pad, a.n_pad = wp.data_ptr(), k_pad, n_pad
@@ -245,6 +253,7 @@ class Graph:
         return run
 
     def _wgrad_call(self, p, m, q, n, out_ptr, B, H, W, taps, flags):
+        self.wgrad_records.append({"flops": 2.0 * B * H * W * taps * m * n, "B": B, "H": H, "W": W, "taps": taps, "m": m, "n": n})
         a = L.WgradArgs()
         a.p, a.ldp, a.m = p.ptr, p.ld, m
         a.q, a.ldq, a.n = q.ptr, q.ld, n
@@ -275,7 +284,7 @@ class Graph:
         wp, taps, n_pad, k_pad = layer.packed("fwd")
         flags = (L.OUT_RELU if relu else 0) | (L.IN_RELU if in_relu else 0)
         self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, res, None, y,
-                                                     x.B, x.H, x.W, flags)))
+                                                     x.B, x.H, x.W, flags, nk=(layer.cout, layer.cin)), "conv_igemm"))
 
         def backward():
             if not y.grad_written:
@@ -283,14 +292,16 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             wflags = L.IN_RELU if in_relu else 0
-            self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags)))
-            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias)))
+            self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags), "conv_wgrad"),
+                     grad_params=[layer.kernel])
+            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias), "bias_grad"), grad_params=[layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gx = x.grad()
                 mask = x if (x.relu or in_relu) else None
                 dflags = L.ACCUM if x.grad_written else 0
-                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, mask, gx, x.B, x.H, x.W, dflags)))
+                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, mask, gx, x.B, x.H, x.W, dflags,
+                                                             nk=(layer.cin, layer.cout)), "conv_igemm"))
                 x.mark_grad_written()
             if res is not None and res.requires_grad:
                 self._masked_add_bwd(res, gy)
@@ -329,20 +340,22 @@ class Graph:
         flags = L.PIXSHUF | (L.OUT_RELU if relu else 0)
         yv = DT(y.buf, y.B, y.H, y.W, 4 * layer.cout, 4 * layer.cout, y.ch0, y.dtype)   # n = (a,b,co)
         self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, yv,
-                                                     x.B, x.H, x.W, flags)))
+                                                     x.B, x.H, x.W, flags, nk=(4 * layer.cout, layer.cin)), "conv_igemm"))
 
         def backward():
             if not y.grad_written:
                 return
             gy = y.grad()
-            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, x, layer.cin, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, 4, L.GATHER2X2)))
-            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias)))
+            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, x, layer.cin, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, 4, L.GATHER2X2), "conv_wgrad"),
+                     grad_params=[layer.kernel])
+            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias), "bias_grad"), grad_params=[layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gx = x.grad()
                 mask = x if x.relu else None
                 dflags = L.GATHER2X2 | (L.ACCUM if x.grad_written else 0)
-                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, mask, gx, x.B, x.H, x.W, dflags)))
+                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, mask, gx, x.B, x.H, x.W, dflags,
+                                                             nk=(layer.cin, layer.cout)), "conv_igemm"))
                 x.mark_grad_written()
         self.on_backward(backward)
         return y
@@ -362,7 +375,7 @@ class Graph:
         ps = self.params
         wp, taps, n_pad, k_pad = layer.packed("fwd")
         self.fwd(self._defer(lambda: self._conv_call(z, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, y,
-                                                     z.B, z.H, z.W, L.OUT_RELU if relu else 0)))
+                                                     z.B, z.H, z.W, L.OUT_RELU if relu else 0, nk=(layer.cout, layer.cin)), "conv_igemm"))
 
         def backward():
             if not y.grad_written:
@@ -370,12 +383,14 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             # out[t][co][ci] = sum_p gy[p (+) t][co] * z[p][ci] == dKernel in TF layout [kh,kw,C_out,C_in]
-            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, z, layer.cin, ps.grad_ptr(layer.kernel), z.B, z.H, z.W, 9, 0)))
-            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias)))
+            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, z, layer.cin, ps.grad_ptr(layer.kernel), z.B, z.H, z.W, 9, 0), "conv_wgrad"),
+                     grad_params=[layer.kernel])
+            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias), "bias_grad"), grad_params=[layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gz = z.grad()
-                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, None, gz, z.B, z.H, z.W, 0)))
+                self.bwd(self._defer(lambda: self._conv_call(gy, wd, dtaps, dn_pad, dk_pad, None, 0, None, None, gz, z.B, z.H, z.W, 0,
+                                                             nk=(layer.cin, layer.cout)), "conv_igemm"))
                 gx = x.grad()
                 mask = x if x.relu else None
                 acc = 1 if x.grad_written else 0
@@ -398,7 +413,7 @@ class Graph:
 
         def run(stream):
             L.check(lib.dd_maxpool_fwd(x.ptr, x.ld, y.ptr, y.ld, idx.data_ptr(), x.Cp, x.B, x.H, x.W, pool, stride, code, stream))
-        self.fwd(run)
+        self.fwd(run, "maxpool")
 
         def backward():
             if not (y.grad_written and x.requires_grad):
@@ -410,14 +425,14 @@ class Graph:
             def runb(stream):
                 L.check(lib.dd_maxpool_bwd(gy.ptr, gy.ld, idx.data_ptr(), gx.ptr, gx.ld, mask.ptr if mask is not None else None,
                                            mask.ld if mask is not None else 0, x.Cp, x.B, x.H, x.W, pool, stride, acc, code, stream))
-            self.bwd(runb)
+            self.bwd(runb, "maxpool")
             x.mark_grad_written()
         self.on_backward(backward)
         return y
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
-    def _defer(make):
+    def _defer(make, tag="pointwise"):
         """Bind a launch lazily: parameter pointers exist only after ParamStore.finalize()."""
         cell = []
 
@@ -425,6 +440,7 @@ class Graph:
             if not cell:
                 cell.append(make())
             cell[0](stream)
+        run.tag = tag
         return run
 
     def finalize(self, seed=2):

@@ -1,0 +1,164 @@
+"""-m gpu: whole hot path (Architecture.predict, loss, backward, Adam) on the HIP path vs the float64 CPU oracle.
+Gate: f32 path within 1e-4 rel-L2 on predictions (BASELINE.json north_star); bf16 path reports its own tolerance."""
+import pytest
+import torch
+
+from deepdenoiser_amd import configs
+from deepdenoiser_amd.naming import Naming
+from gpu_util import check, rel_l2
+from oracle import training as OT
+from oracle.model import OracleArchitecture
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _inputs(oracle, B, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    feats, labels = {}, {}
+    for f in oracle.features + oracle.auxiliary:
+        # HDR-like positive radiance with a few exact zeros (black pixels) and negatives for the normal pass
+        v = torch.randn(B, H, W, f.channels, generator=g).abs() * torch.exp(torch.randn(B, H, W, 1, generator=g))
+        if f.name == "Normal":
+            v = torch.randn(B, H, W, f.channels, generator=g)
+        v[:, :2, :3] = 0.0
+        if not f.load_data:
+            v = torch.full((B, H, W, f.channels), 1.0 if f.ftype == "COLOR" else 0.5)     # Training.py:531-538
+        feats[Naming.source_feature_name(f.name, index=0)] = v
+    for f in oracle.features:
+        t = torch.randn(B, H, W, f.channels, generator=g).abs()
+        if not f.load_data:
+            t = torch.full((B, H, W, f.channels), 1.0 if f.ftype == "COLOR" else 0.5)
+        labels[Naming.target_feature_name(f.name)] = t
+    return feats, labels
+
+
+def _pair(aj, dtype, B, H, W, tj=None):
+    from deepdenoiser_amd.architecture import Architecture
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(oracle, B, H, W)
+    preds_o = oracle.predict(feats)
+    arch = Architecture(aj, device="cuda", dtype=dtype)
+    prog = arch.program(B, H, W, training_json=tj)
+    assert [p.name for p in arch.params.params] == list(oracle.vs.vars.keys())
+    arch.params.load_list(list(oracle.vs.vars.values()))
+    dev = {k: v.cuda() for k, v in feats.items()}
+    devl = {k: v.cuda() for k, v in labels.items()}
+    return oracle, arch, prog, feats, labels, dev, devl, preds_o
+
+
+CASES = {
+    "cfg1_small_unet_direct": (configs.cfg1_small_unet(), 2, 64, 64),
+    "example_json_single_embedding": (configs.architecture(filters=(16, 24, 32), convs=2), 2, 32, 32),
+    "cfg2_unet_kpcn_real_filters": (configs.cfg2_unet_kpcn(), 1, 32, 32),
+    "combined_tuples_kp3": (configs.architecture(tuple_type="COMBINED", filters=(16, 16), convs=1, kernel_size=3, flag_mode="NONE"), 1, 16, 32),
+    "one_hot_no_multiscale_raw_kp_source": (configs.architecture(filters=(16, 16), convs=1, flag_mode="ONE_HOT_ENCODING", multiscale=False,
+                                                                    standardized_kp_source=False,
+                                                                    combined={"Diffuse": {"Color": "Diffuse Color", "Direct": "Diffuse Direct", "Indirect": "Diffuse Indirect"}}), 2, 16, 16),
+    "invert_before_multiscale": (configs.architecture(filters=(16, 16), convs=1, invert_after_multiscale=False, flag_mode="NONE",
+                                                      combined={"Emission": {"Color": "Emission", "Direct": "", "Indirect": ""}}), 2, 32, 16),
+    "tiramisu_multiscale": (configs.cfg3_tiramisu(filters=(16, 24, 32), convs=2), 1, 32, 32),
+}
+
+
+def _with_flags(aj, feats, B, H, W):
+    if aj["architecture"]["source_encoder"]["feature_flag_mode"] != "ONE_HOT_ENCODING":
+        return feats
+    o = OracleArchitecture(aj)
+    names = o.flag_names
+    for i, n in enumerate(names):
+        flags = torch.zeros(B, H, W, len(names))
+        flags[..., i] = 1.0
+        feats[Naming.feature_flags_name(n)] = flags
+    return feats
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward_parity_f32(case):
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    aj, B, H, W = CASES[case]
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, _ = _inputs(oracle, B, H, W)
+    feats = _with_flags(aj, feats, B, H, W)
+    preds_o, internals = oracle.predict(feats, return_internals=True)
+    arch = Architecture(aj, device="cuda", dtype="f32")
+    prog = arch.program(B, H, W)
+    assert [p.name for p in arch.params.params] == list(oracle.vs.vars.keys())
+    arch.params.load_list(list(oracle.vs.vars.values()))
+    preds = arch.predict({k: v.cuda() for k, v in feats.items()})
+    torch.cuda.synchronize()
+    # network input (SourceEncoder) of every tuple
+    T = len(oracle.tuples)
+    xin = prog.X.torch().double().cpu()
+    for t in range(T):
+        check("network_input[%d]" % t, xin[t * B:(t + 1) * B], internals["network_input"][t], 2e-6)
+    assert len(preds) == len(preds_o)
+    worst = 0.0
+    for s, (dp, do) in enumerate(zip(preds, preds_o)):
+        assert sorted(dp.keys()) == sorted(do.keys())
+        for k in do:
+            worst = max(worst, check("scale %d %s" % (s, k), dp[k].cpu(), do[k], 1e-4))
+    print("worst rel-L2 over predictions:", worst)
+
+
+@pytest.mark.parametrize("case", ["cfg1_small_unet_direct", "example_json_single_embedding", "cfg2_unet_kpcn_real_filters", "combined_tuples_kp3",
+                                  "tiramisu_multiscale"])
+def test_training_step_parity_f32(case):
+    """loss, every parameter gradient, and a 3-step Adam trajectory."""
+    _need_gpu()
+    aj, B, H, W = CASES[case]
+    single_feature = len(aj["combined_features"]) == 1
+    tj = configs.bench_training() if single_feature else configs.training()
+    oracle, arch, prog, feats, labels, dev, devl, _ = _pair(aj, "f32", B, H, W, tj)
+    state = ([], [])
+    names = list(oracle.vs.vars.keys())
+    for step in range(1, 4):
+        before = [p.detach().clone() for p in oracle.parameters()]
+        loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, state, step)
+        loss = prog.train_step(dev, devl)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), (step, float(loss), float(loss_o))
+        if step == 1:
+            errs = []
+            for p, n, go in zip(arch.params.params, names, grads_o):
+                if float(go.abs().max()) == 0.0:
+                    assert float(arch.params.grad(p).abs().max()) < 1e-6, n
+                else:
+                    # fp32 atomics / summation order: bias and embedding gradients are near-cancelling sums over all pixels
+                    errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3 if (n.endswith("bias") or "embedding" in n) else 2e-3))
+            errs.sort()
+            print("gradient rel-L2: median %.2e max %.2e" % (errs[len(errs) // 2], errs[-1]))
+        for p, n, po, b4 in zip(arch.params.params, names, oracle.parameters(), before):
+            # compare the UPDATE (Adam normalises the step, so tiny gradient differences may flip noise-level entries)
+            upd, upd_o = arch.params.value(p).double().cpu() - b4, po.detach() - b4
+            diff = (upd - upd_o).abs()
+            assert float(diff.max()) <= 2.1 * tj["learning_rate"], n
+            # Adam normalises every entry to ~lr, so noise-level gradient entries may move differently: bound their share
+            assert float((diff > 0.2 * tj["learning_rate"]).double().mean()) <= 0.03, (step, n)
+            if float(upd_o.norm()) > 0:
+                assert rel_l2(upd, upd_o) < 0.15, (step, n, rel_l2(upd, upd_o))
+
+
+def test_bf16_path_reports_its_tolerance():
+    """Throughput path (bf16 storage, fp32 accumulate): measured, stated tolerance vs the f64 oracle."""
+    _need_gpu()
+    aj, B, H, W = CASES["cfg2_unet_kpcn_real_filters"]
+    tj = configs.bench_training()
+    oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, "bf16", B, H, W, tj)
+    preds = arch.predict(dev)      # inference program (separate from the training program, same parameters)
+    torch.cuda.synchronize()
+    worst = max(rel_l2(dp[k].cpu(), do[k]) for dp, do in zip(preds, preds_o) for k in do)
+    print("bf16 forward worst rel-L2:", worst)
+    assert worst < 3e-2
+    loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    loss = prog.train_step(dev, devl)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_o)) < 3e-2 * abs(float(loss_o))
+    errs = [rel_l2(arch.params.grad(p).cpu(), go) for p, go in zip(arch.params.params, grads_o) if float(go.norm()) > 0]
+    print("bf16 gradient rel-L2: median %.3e max %.3e" % (sorted(errs)[len(errs) // 2], max(errs)))
+    assert sorted(errs)[len(errs) // 2] < 0.25

@@ -1,0 +1,284 @@
+"""-m gpu: hand-written HIP kernels (through the C-ABI + engine) vs the CPU oracle, op by op.
+f32 path: exact-f32 MFMA => tolerance 3e-5 rel-L2; bf16 path: bf16 storage, fp32 accumulate => 2.5e-2."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+from gpu_util import TOL, check, fill, read, rel_l2, representable, set_param
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from deepdenoiser_amd import engine
+    return engine
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_tr16_probe_pins_transpose_read_layout(lib):
+    """ds_read_b64_tr_b16 semantics the bf16 wgrad kernel relies on: within a 16-lane group lane t receives, as element j,
+    the (t%4)-th 16-bit word of the 8 bytes addressed by lane 4*j + t//4."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    img = torch.arange(4096, dtype=torch.int16).cuda()
+    rng = np.random.default_rng(0)
+    addr = (rng.integers(0, 1000, size=64) * 8).astype(np.int32)       # arbitrary 8-byte aligned per-lane addresses
+    a = torch.tensor(addr).cuda()
+    out = torch.zeros(64 * 4, dtype=torch.int16).cuda()
+    assert lib.dd_probe_tr16(img.data_ptr(), a.data_ptr(), out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(64, 4)
+    want = np.zeros((64, 4), dtype=np.int64)
+    for lane in range(64):
+        grp, t = lane // 16, lane % 16
+        for j in range(4):
+            src_lane = grp * 16 + 4 * j + t // 4
+            want[lane, j] = addr[src_lane] // 2 + (t % 4)
+    assert (got == want).all(), (got[:20], want[:20])
+
+
+CONV_CASES = [
+    # k, cin, cout, H, W, relu, in_relu, residual, x_is_relu_output
+    (3, 32, 64, 32, 32, True, False, False, False),
+    (3, 64, 96, 16, 16, True, False, False, True),
+    (3, 192, 96, 16, 16, True, False, False, True),
+    (3, 128, 128, 8, 8, True, False, False, True),
+    (3, 24, 24, 20, 28, False, True, True, False),      # compose-net residual block conv, ragged tile
+    (1, 64, 25, 32, 32, True, False, False, True),      # AdjustNumberOfChannels
+    (1, 25, 25, 32, 32, False, False, False, True),
+    (1, 6, 24, 16, 16, True, False, False, False),
+    (1, 24, 1, 16, 16, True, False, False, False),
+    (3, 3, 16, 24, 24, True, False, False, False),       # cfg-1 first layer
+    (1, 320, 320, 8, 8, False, True, False, False),      # Tiramisu transition-down
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("k,cin,cout,H,W,relu,in_relu,residual,x_relu", CONV_CASES)
+def test_conv_fwd_bwd(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu):
+    B = 2
+    gen = _gen(k * 1000 + cin + cout)
+    g = eng.Graph("cuda", dtype)
+    x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=True)
+    xv = torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64)
+    if x_relu:
+        xv = torch.relu(xv)
+    xv = representable(xv, dtype)
+    res = rv = None
+    if residual:
+        res = g.tensor(B, H, W, cout, requires_grad=True)
+        rv = representable(torch.randn(B, H, W, cout, generator=gen, dtype=torch.float64), dtype)
+    lay = g.layer("t/conv2d", k, cin, cout)
+    y = g.conv(x, lay, relu=relu, in_relu=in_relu, res=res)
+    y.mark_grad_written()
+    g.build_backward()
+    g.finalize()
+    wv = representable(torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) / (k * cin ** 0.5), dtype)
+    bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
+    set_param(g.params, lay.kernel, wv)
+    set_param(g.params, lay.bias, bv)
+    fill(x, xv)
+    if residual:
+        fill(res, rv)
+    g.run(g.pack_ops)
+    g.run(g.fwd_ops)
+    torch.cuda.synchronize()
+
+    xo = xv.clone().requires_grad_(True)
+    wo, bo = wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
+    ro = rv.clone().requires_grad_(True) if residual else None
+    pre = T.conv2d_same(torch.relu(xo) if in_relu else xo, wo, bo, False)
+    if residual:
+        pre = pre + ro
+    yo = torch.relu(pre) if relu else pre
+    tol = TOL[dtype]
+    check("y", read(y), yo.detach(), tol)
+    # pad channels must be exactly zero
+    assert float(y.buf[..., y.C:y.Cp].abs().max() if y.Cp > y.C else 0) == 0.0
+
+    G = torch.randn(B, H, W, cout, generator=gen, dtype=torch.float64)
+    gpre = representable(G * (pre.detach() > 0) if relu else G, dtype)     # engine convention: stored grads are pre-activation
+    fill(y.grad(), gpre)
+    grads = torch.autograd.grad((pre * gpre).sum(), [xo, wo, bo] + ([ro] if residual else []))
+    g.params.grads.zero_()
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    gx_want = grads[0] * (xv > 0) if (x_relu or in_relu) else grads[0]
+    check("dx", read(x.grad()), gx_want, tol * 2)
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
+    if residual:
+        check("dres", read(res.grad()), grads[3], tol)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_grad_accumulation_and_concat_views(eng, dtype):
+    """Two consumers of one tensor (the U-Net skip pattern): first writer overwrites, second accumulates; conv writes into a channel range."""
+    B, H, W, f = 2, 16, 16, 32
+    gen = _gen(7)
+    g = eng.Graph("cuda", dtype)
+    x = g.tensor(B, H, W, 32, requires_grad=True, relu=True)
+    cat = g.tensor(B, H, W, 2 * f, relu=True)
+    l1, l2, l3 = g.layer("a/conv2d", 3, 32, f), g.layer("a/conv2d_1", 3, 32, f), g.layer("a/conv2d_2", 3, 2 * f, 16)
+    g.conv(x, l1, relu=True, out=cat.view(0, f))
+    g.conv(x, l2, relu=True, out=cat.view(f, f))
+    z = g.conv(cat, l3, relu=False)
+    z.mark_grad_written()
+    g.build_backward()
+    g.finalize()
+    xv = representable(torch.relu(torch.randn(B, H, W, 32, generator=gen, dtype=torch.float64)), dtype)
+    ws = []
+    for lay in (l1, l2, l3):
+        w = representable(torch.randn(lay.kernel.shape, generator=gen, dtype=torch.float64) / (3 * lay.cin ** 0.5), dtype)
+        set_param(g.params, lay.kernel, w)
+        ws.append(w.clone().requires_grad_(True))
+    fill(x, xv)
+    g.run(g.pack_ops); g.run(g.fwd_ops)
+    xo = xv.clone().requires_grad_(True)
+    co = torch.cat([T.conv2d_same(xo, ws[0], None, True), T.conv2d_same(xo, ws[1], None, True)], dim=3)
+    zo = T.conv2d_same(co, ws[2], None, False)
+    tol = TOL[dtype]
+    check("cat", read(cat), co.detach(), tol)
+    check("z", read(z), zo.detach(), tol * 2)
+    G = representable(torch.randn(zo.shape, generator=gen, dtype=torch.float64), dtype)
+    fill(z.grad(), G)
+    # the stored activations are rounded to the graph dtype; differentiate the oracle at the same point
+    grads = torch.autograd.grad((zo * G).sum(), [xo] + ws)
+    g.params.grads.zero_()
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    check("dx(accumulated)", read(x.grad()), grads[0] * (xv > 0), tol * 4)
+    for lay, gw in zip((l1, l2, l3), grads[1:]):
+        check("dW " + lay.name, g.params.grad(lay.kernel).double().cpu(), gw, tol * 4)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 96, 8, 8), (96, 64, 16, 16), (32, 16, 12, 20)])
+def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
+    B = 2
+    gen = _gen(cin + cout)
+    g = eng.Graph("cuda", dtype)
+    x = g.tensor(B, H, W, cin, relu=True, requires_grad=True)
+    cat = g.tensor(B, 2 * H, 2 * W, 2 * cout, relu=True)
+    lay = g.layer("t/conv2d_transpose", 2, cin, cout, "convT2")
+    y = g.conv_transpose2(x, lay, out=cat.view(cout, cout), relu=True)
+    y.mark_grad_written()
+    g.build_backward()
+    g.finalize()
+    xv = representable(torch.relu(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64)), dtype)
+    wv = representable(torch.randn(2, 2, cout, cin, generator=gen, dtype=torch.float64) / cin ** 0.5, dtype)
+    bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
+    set_param(g.params, lay.kernel, wv); set_param(g.params, lay.bias, bv)
+    fill(x, xv)
+    g.run(g.pack_ops); g.run(g.fwd_ops)
+    xo, wo, bo = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
+    pre = T.conv2d_transpose_s2(xo, wo, bo, False)
+    tol = TOL[dtype]
+    check("y", read(y), torch.relu(pre).detach(), tol)
+    assert float(cat.buf[..., :cout].abs().max()) == 0.0       # the skip half of the concat buffer is untouched
+    G = torch.randn(pre.shape, generator=gen, dtype=torch.float64)
+    gpre = representable(G * (pre.detach() > 0), dtype)
+    fill(y.grad(), gpre)
+    grads = torch.autograd.grad((pre * gpre).sum(), [xo, wo, bo])
+    g.params.grads.zero_()
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    check("dx", read(x.grad()), grads[0] * (xv > 0), tol * 2)
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_transpose_3x3(eng, dtype):
+    B, H, W, cin, cout = 2, 8, 8, 64, 24
+    gen = _gen(33)
+    g = eng.Graph("cuda", dtype)
+    x = g.tensor(B, H, W, cin, requires_grad=True)
+    lay = g.layer("t/conv2d_transpose", 3, cin, cout, "convT3")
+    y = g.conv_transpose3(x, lay, relu=True)
+    y.mark_grad_written()
+    g.build_backward()
+    g.finalize()
+    xv = representable(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64), dtype)
+    wv = representable(torch.randn(3, 3, cout, cin, generator=gen, dtype=torch.float64) / (3 * cin ** 0.5), dtype)
+    bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
+    set_param(g.params, lay.kernel, wv); set_param(g.params, lay.bias, bv)
+    fill(x, xv)
+    g.run(g.pack_ops); g.run(g.fwd_ops)
+    xo, wo, bo = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
+    pre = T.conv2d_transpose_s2(xo, wo, bo, False)
+    tol = TOL[dtype]
+    check("y", read(y), torch.relu(pre).detach(), tol)
+    G = torch.randn(pre.shape, generator=gen, dtype=torch.float64)
+    gpre = representable(G * (pre.detach() > 0), dtype)
+    fill(y.grad(), gpre)
+    grads = torch.autograd.grad((pre * gpre).sum(), [xo, wo, bo])
+    g.params.grads.zero_()
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    check("dx", read(x.grad()), grads[0], tol * 2)
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("pool,stride,H,W", [(3, 2, 16, 16), (3, 2, 10, 14), (2, 2, 8, 12)])
+def test_maxpool(eng, dtype, pool, stride, H, W):
+    B, C = 2, 16
+    gen = _gen(pool * 10 + H)
+    g = eng.Graph("cuda", dtype)
+    x = g.tensor(B, H, W, C, relu=True, requires_grad=True)
+    y = g.maxpool(x, pool, stride)
+    y.mark_grad_written()
+    g.build_backward()
+    g.finalize()
+    xv = representable(torch.relu(torch.randn(B, H, W, C, generator=gen, dtype=torch.float64)) + 0.0, dtype)
+    fill(x, xv)
+    g.run(g.fwd_ops)
+    xo = xv.clone().requires_grad_(True)
+    yo = T.max_pool_same(xo, pool, stride)
+    check("y", read(y), yo.detach(), 1e-7)
+    G = representable(torch.randn(yo.shape, generator=gen, dtype=torch.float64), dtype)
+    fill(y.grad(), G)
+    (gx,) = torch.autograd.grad((yo * G).sum(), [xo])
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    # exact ties only happen at 0 (ReLU), where the mask kills the gradient anyway
+    check("dx", read(x.grad()), gx * (xv > 0), 2e-3 if dtype == "bf16" else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("ks", [3, 5])
+def test_kernel_prediction_apply(lib, eng, dtype, ks):
+    from deepdenoiser_amd import _lib as L
+    B, H, W = 2, 12, 20
+    k2 = ks * ks
+    ld = 32
+    gen = _gen(ks)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    code = L.DD_F32 if dtype == "f32" else L.DD_BF16
+    src = torch.randn(B, H, W, 4, generator=gen).cuda()
+    lg = representable(torch.randn(B, H, W, ld, generator=gen, dtype=torch.float64) * 2, dtype)
+    lgd = lg.to(tdt).cuda()
+    out = torch.zeros(B, H, W, 3).cuda()
+    L.check(lib.dd_kpcn_fwd(src.data_ptr(), 4, lgd.data_ptr(), ld, out.data_ptr(), 3, B, H, W, ks, code, None))
+    so = src[..., :3].double().cpu()
+    lo = lg[..., :k2].clone().requires_grad_(True)
+    oo = T.kernel_prediction(so, lo, ks)
+    check("kp out", out.cpu(), oo.detach(), 2e-5)
+    G = torch.randn(B, H, W, 3, generator=gen)
+    (gl,) = torch.autograd.grad((oo * G.double()).sum(), [lo])
+    dl = torch.full((B, H, W, ld), 7.0, dtype=tdt).cuda()
+    L.check(lib.dd_kpcn_bwd(src.data_ptr(), 4, lgd.data_ptr(), ld, G.cuda().data_ptr(), 3, dl.data_ptr(), ld, ld, B, H, W, ks, code, None))
+    torch.cuda.synchronize()
+    check("kp dlogits", dl[..., :k2].cpu(), gl, 2e-5 if dtype == "f32" else 1e-2)
+    assert float(dl[..., k2:].float().abs().max()) == 0.0
