@@ -20,7 +20,7 @@ SYMBOLS = (
     "dd_maxpool_fwd", "dd_maxpool_bwd", "dd_avgpool", "dd_prepare_feature", "dd_gather_input",
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
-    "dd_stitch", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
+    "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
 )
 
 
@@ -69,7 +69,12 @@ class LossDesc(C.Structure):
 
 class StitchEntry(C.Structure):
     _fields_ = [("tile", C.c_int), ("crop_y0", C.c_int), ("crop_y1", C.c_int), ("crop_x0", C.c_int),
-                ("crop_x1", C.c_int), ("dst_y", C.c_int), ("dst_x", C.c_int)]
+                ("crop_x1", C.c_int), ("dst_img", C.c_int), ("dst_y", C.c_int), ("dst_x", C.c_int)]
+
+
+class RecombineDesc(C.Structure):
+    _fields_ = [("n_triples", C.c_int), ("color", C.c_void_p * 4), ("direct", C.c_void_p * 4), ("indirect", C.c_void_p * 4),
+                ("combined", C.c_void_p * 4), ("n_singles", C.c_int), ("single", C.c_void_p * 8), ("image", C.c_void_p)]
 
 
 _lib = None
@@ -80,6 +85,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's): it must be loaded FIRST so that this library binds
+    # to the runtime that owns torch's streams and allocations (otherwise two runtimes coexist and no device is found).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libdd_hip.so is not built (%s missing): run `python -m deepdenoiser_amd.build`. "
                            "There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
@@ -112,6 +120,7 @@ def load():
     lib.dd_loss_head.argtypes = [C.POINTER(LossDesc), i, i, i, vp, f, vp]
     lib.dd_adam_step.argtypes = [vp, vp, vp, vp, l, f, f, f, f, f, vp]
     lib.dd_stitch.argtypes = [vp, i, i, vp, i, i, i, i, vp, i, vp]
+    lib.dd_recombine.argtypes = [C.POINTER(RecombineDesc), l, vp]
     lib.dd_probe_tr16.argtypes = [vp, vp, vp, vp]
     lib.dd_masked_add.argtypes = [vp, i, vp, i, vp, i, i, l, i, i, vp]
     lib.dd_convert_channels.argtypes = [vp, i, i, vp, i, i, i, i, l, vp]

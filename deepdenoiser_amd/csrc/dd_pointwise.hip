@@ -728,7 +728,7 @@ __global__ void stitch_kernel(const float* __restrict__ tiles, int ts, int ldt, 
     const int c = (int)(i % C);
     const long r = i / C;
     const int x = (int)(r % cw), y = (int)(r / cw);
-    frame[((long)(e.dst_y + y) * fw + e.dst_x + x) * ldf + c] =
+    frame[(((long)e.dst_img * fh + e.dst_y + y) * fw + e.dst_x + x) * ldf + c] =
         tiles[(((long)e.tile * ts + e.crop_y0 + y) * ts + e.crop_x0 + x) * ldt + c];
   }
 }
@@ -736,6 +736,26 @@ extern "C" int dd_stitch(const float* tiles, int tile_size, int ldt, float* fram
                          const dd_stitch_entry* table, int n_entries, dd_stream stream) {
   DD_REQUIRE(tiles && frame && table && n_entries > 0, "dd_stitch: bad arguments");
   hipLaunchKernelGGL(stitch_kernel, dim3(n_entries), dim3(256), 0, S(stream), tiles, tile_size, ldt, frame, frame_h, frame_w, ldf, C, table);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+__global__ void recombine_kernel(const dd_recombine_desc d, long npix) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= npix * 3) return;
+  float img = 0.f;
+  for (int k = 0; k < d.n_triples; ++k) {
+    const float v = d.color[k][i] * (d.direct[k][i] + d.indirect[k][i]);
+    if (d.combined[k]) d.combined[k][i] = v;
+    img += v;       // same left-to-right order as the np.add chain of Prediction.py:466-481
+  }
+  for (int j = 0; j < d.n_singles; ++j) img += d.single[j][i];
+  d.image[i] = img;
+}
+extern "C" int dd_recombine(const dd_recombine_desc* desc, long npix, dd_stream stream) {
+  DD_REQUIRE(desc && desc->image && desc->n_triples >= 0 && desc->n_triples <= 4 && desc->n_singles >= 0 && desc->n_singles <= 8 && npix > 0,
+             "dd_recombine: bad descriptor");
+  hipLaunchKernelGGL(recombine_kernel, dim3(grid_for(npix * 3)), dim3(256), 0, S(stream), *desc, npix);
   DD_LAUNCH_CHECK();
   return DD_OK;
 }

@@ -1,0 +1,91 @@
+"""Full-frame inference: halo tiling -> batched forward on the HIP path -> on-device crop/stitch -> recombination.
+
+Mirrors the reference's Prediction.main (TensorFlow/Prediction.py:188-520) for the part that is on the hot path:
+the integer tile plan and crop windows (bit-exact, tiling.py), row-major tile order (:325-326, :380-382), stitch
+(:384-441) and recombination (:443-481).  Differences by design: tiles are batched
+(the reference's batch-1 Estimator.predict and its temporary TFRecord round trip, :316-338, are not part of the
+contract), and crop/stitch/recombine run on the device.  EXR decode (cv2) is out of scope: frames are given as
+tensors keyed by the reference's feature names.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .naming import Naming
+from .tiling import tile_plan
+
+_COMBINED = ("Diffuse", "Glossy", "Subsurface", "Transmission")
+_SINGLES = ("Volume Direct", "Volume Indirect", "Environment", "Emission")
+
+
+class Predictor:
+    def __init__(self, architecture, tile_size=128, tile_overlap_size=14, tiles_per_batch=16):
+        self.arch, self.tile_size, self.tile_overlap_size, self.tiles_per_batch = architecture, tile_size, tile_overlap_size, tiles_per_batch
+        self.lib = L.load()
+
+    def predict_frame(self, features):
+        """features: {'source_image/0/<Pass>': [H,W,C] float32 tensor} -> {'prediction/<Pass>': [H,W,C]} (+ 'Combined' if all passes exist)."""
+        arch, lib = self.arch, self.lib
+        dev = arch.device
+        names = arch.required_source_names()
+        frame = {k: torch.as_tensor(features[k], dtype=torch.float32).to(dev) for k in names}
+        H, W = frame[names[0]].shape[0], frame[names[0]].shape[1]
+        plan = tile_plan(H, W, self.tile_size, self.tile_overlap_size)
+        T = plan.tile
+        Bt = min(self.tiles_per_batch, plan.count)
+        prog = arch.program(Bt, T, T)
+        NF = prog.NF
+        frames = torch.zeros((NF, H, W, 3), dtype=torch.float32, device=dev)
+        origins = plan.windows()
+        grid = [(hi, wi) for hi in range(plan.rows.count) for wi in range(plan.cols.count)]    # row-major
+        prog.pack_weights()
+        stream = prog.g.stream_ptr()
+        for start in range(0, plan.count, Bt):
+            chunk = list(range(start, min(start + Bt, plan.count)))
+            tiled = {}
+            for k in names:
+                src = frame[k]
+                buf = torch.zeros((Bt, T, T, src.shape[2]), dtype=torch.float32, device=dev)
+                for slot, ti in enumerate(chunk):
+                    y0, x0 = origins[ti]
+                    buf[slot] = src[y0:y0 + T, x0:x0 + T]
+                tiled[k] = buf
+            prog.set_inputs(tiled)
+            prog.forward(pack=False)
+            tiles = prog.predictions[0]                                  # [NF*Bt, T, T, 3], feature-major
+            table = (L.StitchEntry * (len(chunk) * NF))()
+            n = 0
+            for f in range(NF):
+                for slot, ti in enumerate(chunk):
+                    hi, wi = grid[ti]
+                    (cy0, cy1), (cx0, cx1) = plan.rows.crops[hi], plan.cols.crops[wi]
+                    table[n] = L.StitchEntry(f * Bt + slot, cy0, cy1, cx0, cx1, f, plan.rows.offsets[hi], plan.cols.offsets[wi])
+                    n += 1
+            tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+            L.check(lib.dd_stitch(tiles.ptr, T, 3, frames.data_ptr(), H, W, 3, 3, tdev.data_ptr(), n, stream))
+        out = {}
+        for f in arch.feature_predictions:
+            if f.is_target and f.load_data:
+                out[Naming.feature_prediction_name(f.name)] = frames[prog.head_index[f.name]][..., :f.number_of_channels]
+        self._recombine(prog, frames, out, H * W, stream)
+        return out
+
+    def _recombine(self, prog, frames, out, npix, stream):
+        idx = prog.head_index
+        need = [c + s for c in _COMBINED for s in (" Color", " Direct", " Indirect")] + list(_SINGLES)
+        if not all(n in idx and prog.head[idx[n]].load_data for n in need):
+            return
+        comb = torch.zeros((len(_COMBINED) + 1,) + tuple(frames.shape[1:]), dtype=torch.float32, device=frames.device)
+        d = L.RecombineDesc()
+        d.n_triples = len(_COMBINED)
+        for k, c in enumerate(_COMBINED):
+            d.color[k], d.direct[k], d.indirect[k] = (frames[idx[c + s]].data_ptr() for s in (" Color", " Direct", " Indirect"))
+            d.combined[k] = comb[k].data_ptr()
+            out[Naming.feature_prediction_name(c)] = comb[k]
+        d.n_singles = len(_SINGLES)
+        for j, s in enumerate(_SINGLES):
+            d.single[j] = frames[idx[s]].data_ptr()
+        d.image = comb[len(_COMBINED)].data_ptr()
+        L.check(self.lib.dd_recombine(C.byref(d), npix, stream))
+        out["Combined"] = comb[len(_COMBINED)]

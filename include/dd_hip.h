@@ -173,9 +173,19 @@ int dd_adam_step(float* params, const float* grads, float* m, float* v, long n, 
                  float eps, float grad_scale, dd_stream stream);
 
 /* ---- inference stitch (Prediction.py:384-441): copy crop windows of row-major tiles into the frame */
-typedef struct { int tile; int crop_y0, crop_y1, crop_x0, crop_x1; int dst_y, dst_x; } dd_stitch_entry;
-int dd_stitch(const float* tiles, int tile_size, int ldt, float* frame, int frame_h, int frame_w, int ldf, int C,
+typedef struct { int tile; int crop_y0, crop_y1, crop_x0, crop_x1; int dst_img, dst_y, dst_x; } dd_stitch_entry;
+/* frames: [n_img, frame_h, frame_w, ldf]; entry copies tiles[tile][crop] to frames[dst_img] at (dst_y, dst_x) */
+int dd_stitch(const float* tiles, int tile_size, int ldt, float* frames, int frame_h, int frame_w, int ldf, int C,
               const dd_stitch_entry* table, int n_entries, dd_stream stream);
+
+/* ---- recombination (Prediction.py:443-481): image = sum_k color_k*(direct_k+indirect_k) + sum_j single_j ; also writes each
+ * combined_k if combined[k] != NULL.  All tensors [npix, 3] fp32 contiguous. */
+typedef struct {
+  int n_triples; const float* color[4]; const float* direct[4]; const float* indirect[4]; float* combined[4];
+  int n_singles; const float* single[8];
+  float* image;
+} dd_recombine_desc;
+int dd_recombine(const dd_recombine_desc* desc, long npix, dd_stream stream);
 
 /* ---- small helpers of the graph executor */
 /* dst (+)= src * (mask > 0)   (identity/residual gradient paths into ReLU outputs); mask may be NULL */
