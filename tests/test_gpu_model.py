@@ -117,32 +117,33 @@ def test_training_step_parity_f32(case):
     oracle, arch, prog, feats, labels, dev, devl, _ = _pair(aj, "f32", B, H, W, tj)
     state = ([], [])
     names = list(oracle.vs.vars.keys())
+    start = [p.detach().clone() for p in oracle.parameters()]
     for step in range(1, 4):
-        before = [p.detach().clone() for p in oracle.parameters()]
         loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, state, step)
         loss = prog.train_step(dev, devl)
         torch.cuda.synchronize()
-        assert abs(float(loss) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), (step, float(loss), float(loss_o))
+        # step 1 is a pure function of identical weights; later steps compare two (slightly diverging) trajectories
+        tol = 2e-5 if step == 1 else 1e-3
+        assert abs(float(loss) - float(loss_o)) <= tol * abs(float(loss_o)), (step, float(loss), float(loss_o))
         if step == 1:
             errs = []
             for p, n, go in zip(arch.params.params, names, grads_o):
                 if float(go.abs().max()) == 0.0:
                     assert float(arch.params.grad(p).abs().max()) < 1e-6, n
                 else:
-                    # fp32 atomics / summation order: bias and embedding gradients are near-cancelling sums over all pixels
                     # f32 vs f64 oracle: a handful of ReLU / sign(p-t) decisions flip at noise-level pre-activations => tolerance 5e-3, median reported
                     errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
             errs.sort()
             print("gradient rel-L2: median %.2e max %.2e" % (errs[len(errs) // 2], errs[-1]))
-        for p, n, po, b4 in zip(arch.params.params, names, oracle.parameters(), before):
-            # compare the UPDATE (Adam normalises the step, so tiny gradient differences may flip noise-level entries)
-            upd, upd_o = arch.params.value(p).double().cpu() - b4, po.detach() - b4
-            diff = (upd - upd_o).abs()
-            assert float(diff.max()) <= 2.1 * tj["learning_rate"], n
-            # Adam normalises every entry to ~lr, so noise-level gradient entries may move differently: bound their share
-            assert float((diff > 0.2 * tj["learning_rate"]).double().mean()) <= max(0.03, 1.5 / diff.numel()), (step, n)
-            if float(upd_o.norm()) > 0:
-                assert rel_l2(upd, upd_o) < 0.15, (step, n, rel_l2(upd, upd_o))
+    # 3-step displacement.  Adam normalises every entry's step to ~lr, so noise-level gradient entries may move differently
+    # (the Adam kernel itself is checked exactly in test_gpu_ops.test_adam_tf_form): compare displacements statistically.
+    lr = tj["learning_rate"]
+    for p, n, po, p0 in zip(arch.params.params, names, oracle.parameters(), start):
+        d, do = arch.params.value(p).double().cpu() - p0, po.detach() - p0
+        assert float((d - do).abs().max()) <= 2.0 * 3 * lr + 1e-9, n
+        if float(do.norm()) > 0:
+            assert rel_l2(d, do) < 0.2, (n, rel_l2(d, do))
+            assert float(((d - do).abs() > 0.5 * lr).double().mean()) <= max(0.08, 2.0 / d.numel()), n
 
 
 def test_bf16_path_reports_its_tolerance():

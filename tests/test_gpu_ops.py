@@ -65,7 +65,16 @@ CONV_CASES = [
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("k,cin,cout,H,W,relu,in_relu,residual,x_relu", CONV_CASES)
 def test_conv_fwd_bwd(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu):
-    B = 2
+    _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B=2)
+
+
+@pytest.mark.parametrize("k,cin,cout,H,W,B", [(1, 16, 27, 16, 32, 8), (1, 27, 27, 16, 32, 8), (3, 32, 16, 16, 32, 8), (1, 24, 1, 16, 32, 24),
+                                               (3, 24, 24, 16, 32, 24), (1, 16, 27, 8, 16, 8), (3, 16, 16, 32, 16, 5), (3, 16, 16, 48, 16, 3)])
+def test_conv_non_square_batches(eng, k, cin, cout, H, W, B):
+    _conv_case(eng, "f32", k, cin, cout, H, W, True, False, False, True, B=B)
+
+
+def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B):
     gen = _gen(k * 1000 + cin + cout)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=True)
@@ -282,3 +291,72 @@ def test_kernel_prediction_apply(lib, eng, dtype, ks):
     torch.cuda.synchronize()
     check("kp dlogits", dl[..., :k2].cpu(), gl, 2e-5 if dtype == "f32" else 1e-2)
     assert float(dl[..., k2:].float().abs().max()) == 0.0
+
+
+def test_adam_tf_form(lib):
+    """dd_adam_step == tf.train.AdamOptimizer update (eps NOT bias-corrected), 4 steps, flat arena."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import math
+    from deepdenoiser_amd import _lib as L
+    gen = _gen(5)
+    n = 10007
+    p0 = torch.randn(n, generator=gen)
+    p = p0.clone().cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
+    po = [p0.double().clone()]; mo = [torch.zeros(n, dtype=torch.float64)]; vo = [torch.zeros(n, dtype=torch.float64)]
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=gen) * torch.exp(3 * torch.randn(n, generator=gen))      # gradients over many magnitudes
+        gr[::17] = 0.0
+        lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        L.check(lib.dd_adam_step(p.data_ptr(), gr.cuda().data_ptr(), m.data_ptr(), v.data_ptr(), n, lr_t, b1, b2, eps, 0.5, None))
+        T.adam_step(po, [0.5 * gr.double()], mo, vo, step, lr)
+        torch.cuda.synchronize()
+        assert float((p.double().cpu() - po[0]).abs().max()) < 2e-6
+        check("m", m.cpu(), mo[0], 1e-6)
+        check("v", v.cpu(), vo[0], 1e-6)
+
+
+def test_stitch_and_recombine_bit_exact(lib):
+    """Crop/stitch through the C-ABI == the literal restatement of Prediction.py:384-441 (bit exact); recombination :443-481."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from deepdenoiser_amd import _lib as L
+    from deepdenoiser_amd.tiling import tile_plan
+    from oracle import tiling_ref
+    H, W, Tt = 300, 420, 128
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((H, W, 3)).astype(np.float32)
+    plan = tile_plan(H, W)
+    tiles = np.stack([img[y:y + Tt, x:x + Tt] for (y, x) in plan.windows()])
+    grid = [(hi, wi) for hi in range(plan.rows.count) for wi in range(plan.cols.count)]
+    table = (L.StitchEntry * len(grid))()
+    for i, (hi, wi) in enumerate(grid):
+        (a, b), (c, d) = plan.rows.crops[hi], plan.cols.crops[wi]
+        table[i] = L.StitchEntry(i, a, b, c, d, 0, plan.rows.offsets[hi], plan.cols.offsets[wi])
+    td = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).cuda()
+    tiles_d = torch.tensor(tiles).cuda()
+    frame = torch.full((1, H, W, 3), -7.0).cuda()
+    L.check(lib.dd_stitch(tiles_d.data_ptr(), Tt, 3, frame.data_ptr(), H, W, 3, 3, td.data_ptr(), len(grid), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(frame[0].cpu().numpy(), img)
+    rows = [[tiles[hi * plan.cols.count + wi] for wi in range(plan.cols.count)] for hi in range(plan.rows.count)]
+    assert np.array_equal(tiling_ref.stitch(rows, H, W), img)
+    # recombination
+    names = [c + s for c in ("Diffuse", "Glossy", "Subsurface", "Transmission") for s in (" Color", " Direct", " Indirect")] + ["Volume Direct", "Volume Indirect", "Environment", "Emission"]
+    passes = {n: rng.standard_normal((50, 40, 3)).astype(np.float32) for n in names}
+    dev = {n: torch.tensor(v).cuda() for n, v in passes.items()}
+    out = torch.zeros(50, 40, 3).cuda()
+    d = L.RecombineDesc()
+    d.n_triples = 4
+    for k, c in enumerate(("Diffuse", "Glossy", "Subsurface", "Transmission")):
+        d.color[k], d.direct[k], d.indirect[k] = dev[c + " Color"].data_ptr(), dev[c + " Direct"].data_ptr(), dev[c + " Indirect"].data_ptr()
+    d.n_singles = 4
+    for j, n in enumerate(("Volume Direct", "Volume Indirect", "Environment", "Emission")):
+        d.single[j] = dev[n].data_ptr()
+    d.image = out.data_ptr()
+    L.check(lib.dd_recombine(C.byref(d), 50 * 40, None))
+    torch.cuda.synchronize()
+    want = tiling_ref.recombine(passes)
+    assert np.allclose(out.cpu().numpy(), want, rtol=0, atol=1e-5)     # fp32 fma contraction vs numpy: not bit-exact by design
