@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdd_hip.so")
+LIB_PATH = os.environ.get("DD_LIB", os.path.join(_HERE, "libdd_hip.so"))   # DD_LIB: experiment builds (tools/)
 
 DD_F32, DD_BF16 = 0, 1
 IN_RELU, OUT_RELU, ACCUM, PIXSHUF, GATHER2X2 = 1, 2, 4, 8, 16

@@ -35,12 +35,14 @@ void dd_set_error(const char* fmt, ...);
 
 // ------------------------------------------------------------------------------------------------ element helpers
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest even
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// round to nearest even in hardware: the native __bf16 casts lower to v_cvt_pk_bf16_f32 on gfx950 (one VALU op per PAIR;
+// a software rounding sequence costs ~7 ops per element and made the conv epilogue VALU-issue bound)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -86,9 +88,35 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
   uint2 t;
-  t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  t.x = pack_bf16x2(v[0], v[1]);
+  t.y = pack_bf16x2(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
+}
+
+// 8 bf16 (one 16-byte vector) <-> float[8]
+__device__ __forceinline__ void unpack8(uint4 u, float (&v)[8]) {
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  uint4 u;
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
+  u.z = pack_bf16x2(v[4], v[5]);
+  u.w = pack_bf16x2(v[6], v[7]);
+  return u;
+}
+// keep the bf16 lanes of `v` whose mask lane is > 0 (ReLU-backward on packed data, no unpacking)
+__device__ __forceinline__ uint32_t mask_bf16x2(uint32_t v, uint32_t m) {
+  const uint32_t lo = ((m & 0x8000u) == 0u && (m & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+  const uint32_t hi = ((m & 0x80000000u) == 0u && (m & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+  return v & (lo | hi);
+}
+__device__ __forceinline__ uint4 mask_bf16x8(uint4 v, uint4 m) {
+  v.x = mask_bf16x2(v.x, m.x); v.y = mask_bf16x2(v.y, m.y); v.z = mask_bf16x2(v.z, m.z); v.w = mask_bf16x2(v.w, m.w);
+  return v;
 }
 
 template <typename T> __device__ __forceinline__ float ld1(const T* p) { return Elem<T>::to_f32(*p); }
@@ -124,11 +152,11 @@ __device__ __forceinline__ void stage_pixels(char* lds, const T* __restrict__ x,
     const int ly = g.oy + py, lx = g.ox + px;
     const int gy = ly * g.sy + g.ay, gx = lx * g.sy + g.ax;
     const int ch = ch0 + slot * PER16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ly >= g.min_y && lx >= g.min_x && ly < g.lim_y && lx < g.lim_x && gy >= 0 && gx >= 0 && gy < g.hin && gx < g.win && ch < cin) {
-      v = *reinterpret_cast<const uint4*>(x + (img_base + (long)gy * g.win + gx) * ldx + ch);
-      if (in_relu) v = relu16<T>(v);
-    }
+    // unconditional load from a clamped address + select (a branch per vector would serialise the loads on vmcnt(0))
+    const bool ok = ly >= g.min_y && lx >= g.min_x && ly < g.lim_y && lx < g.lim_x && gy >= 0 && gx >= 0 && gy < g.hin && gx < g.win && ch < cin;
+    uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? (img_base + (long)gy * g.win + gx) * ldx + ch : 0));
+    if (in_relu) v = relu16<T>(v);
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
     *reinterpret_cast<uint4*>(lds + lds_off(pix, slot)) = v;
   }
 }

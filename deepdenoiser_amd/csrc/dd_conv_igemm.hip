@@ -4,16 +4,40 @@
 // Tiramisu.py:35-37,50-52,77-79, Architecture.py:238-243, MultiScalePrediction.py:64-66,73-75,88-90),
 // tf.layers.conv2d_transpose 2x2/s2 (UNet.py:56-58) and their TF-autodiff input gradients (Training.py:701-702).
 //
-// Mapping.  A workgroup (4 waves) owns a 16x16 pixel tile of one image and NT*16 output channels.
-//   GEMM: D[cout][pixel] = sum_{tap, cin} Wp[tap][cout][cin] * X[pixel (+) tap][cin]
-//   "A" operand = packed weights (rows = cout), "B" operand = pixels (cols), so after the MFMA every lane holds
-//   4 CONSECUTIVE output channels of one pixel -> packed 8/16-byte NHWC stores, fused bias/ReLU/mask epilogue.
-// Data movement.  Per 128-byte K-slice of input channels (64 bf16 / 32 f32) the (16+2)^2 halo patch is staged in LDS
-// ONCE and reused by all 9 taps (9x less L2->LDS traffic than im2col); the weight slab of one (tap, K-slice) is
-// double-buffered so there is one barrier per tap.  LDS rows are 128 B with a 16-byte-slot XOR swizzle
-// (dd_common.h: lds_off) => ds_read_b128 fragment reads are bank-conflict free.
-// LDS: 40.5 KiB patch + 2 * NT*2 KiB weights (<= 72.5 KiB) => 2 workgroups per CU overlap staging with MFMA.
+// Mapping.  GEMM: D[cout][pixel] = sum_{tap, cin} Wp[tap][cout][cin] * X[pixel (+) tap][cin].
+//   "A" operand = packed weights (rows = cout), "B" operand = pixels (cols): after the MFMA every lane holds 4 CONSECUTIVE
+//   output channels of one pixel -> packed 8/16-byte NHWC stores with the bias/residual/ReLU/mask/accumulate epilogue fused.
+// Schedule (v2: persistent + software pipelined).  One workgroup (4 waves, one per SIMD) per CU walks a strided list of
+//   16x16-pixel tiles for a fixed block of NT*16 output channels.  A "unit" = one 128-byte K-slice (64 bf16 / 32 f32
+//   channels) of one tile: its (16+2)^2 halo patch is staged in LDS ONCE and reused by all 9 taps.  While the MFMAs of
+//   unit u run, the global loads of unit u+1's patch are already in flight into registers (written to the other LDS
+//   buffer after the compute, one barrier per unit).  Weights: if all (tap, slice) slabs of the layer fit next to the two
+//   patch buffers they are loaded ONCE per workgroup and stay resident (no per-tap traffic or barriers at all: 288 MFMAs
+//   per wave back to back for a 64->64 layer); otherwise the slab of the next tap is register-prefetched during the
+//   current tap's MFMAs (one barrier per tap, latency hidden).
+// LDS rows are 128 B with a 16-byte-slot XOR swizzle (dd_common.h: lds_off) => ds_read_b128 fragment reads are
+// bank-conflict free.
+#include <stdlib.h>
+
 #include "dd_common.h"
+
+#ifdef DD_PROFILE_PHASES
+__device__ unsigned long long dd_phase_cycles[8];
+#define PHASE_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PHASE_ADD(i, a, b) if (blockIdx.x == 0 && tid == 0) dd_phase_cycles[i] += (b) - (a)
+extern "C" int dd_debug_phases(unsigned long long* out8, int reset) {
+  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(dd_phase_cycles), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_phase_cycles), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define PHASE_T(var)
+#define PHASE_ADD(i, a, b)
+#endif
+
+// 16 bytes of zeros: invalid vectors (outside the image / channels >= cin) are read from here, so every load of a patch is
+// unconditional and needs no select afterwards.
+__device__ uint4 dd_zero16 = {0u, 0u, 0u, 0u};
 
 namespace {
 
@@ -21,171 +45,481 @@ struct ConvP {
   const void* x; const void* wp; const float* bias; const void* res; const void* mask; void* y;
   int ldx, cin, k_pad, n_pad, ldres, ldmask, ldy, n;
   int B, H, W, taps, flags, nbias;
-  int tiles_x, tiles_y, nblk;   // grid decomposition
+  int tiles_x, tiles_y, nblk;   // tile grid and number of output-channel blocks
   int kchunks;                  // number of 64-byte K chunks (k_pad*sizeof(T)/64)
   int hin, win;                 // input image size
   int hout, wout;               // output image size
+  int total_tiles;              // B * tiles_y * tiles_x
 };
 
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WB = NT * 16 * DD_LDS_ROW;  // bytes of one weight slab
-  const bool halo = (p.taps == 9);
-  const bool gather = (p.flags & DD_GATHER2X2) != 0;
-  const int ph = halo ? DD_TILE + 2 : DD_TILE, pw = ph;
-  char* patch = smem;
-  char* wbuf = smem + ph * pw * DD_LDS_ROW;
+template <bool HALO> struct PatchDim {
+  static constexpr int PH = HALO ? DD_TILE + 2 : DD_TILE;
+  static constexpr int NPIX = PH * PH;
+  static constexpr int ITERS = (NPIX * 8 + 255) / 256;
+};
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
-  const int nb = bid % p.nblk; bid /= p.nblk;
-  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
-  const int ty = bid % p.tiles_y; bid /= p.tiles_y;
-  const int b = bid;
-  const int y0 = ty * DD_TILE, x0 = tx * DD_TILE, n0 = nb * NT * 16;
+// Per-thread staging plan of a patch K-slice, computed ONCE per workgroup (the kernel is VALU-issue bound: per-vector index
+// arithmetic must not be repeated per tile).  Vector `it` of this thread covers patch pixel (py,px) = yx[it]; rel[it] is its
+// element offset from the patch origin pixel in the input image; lds[it] its byte offset in the LDS image.
+template <bool HALO> struct PatchPlan {
+  int yx[PatchDim<HALO>::ITERS];     // (py << 8) | px, or -1 when the vector is outside the patch
+  int rel[PatchDim<HALO>::ITERS];
+  int lds[PatchDim<HALO>::ITERS];
+};
 
-  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.wp);
-  const long img_base = (long)b * p.hin * p.win;
-  const bool in_relu = (p.flags & DD_IN_RELU) != 0;
-
-  f32x4_t acc[NT][4];
+template <bool HALO>
+__device__ __forceinline__ void patch_plan(PatchPlan<HALO>& pl, const ConvP& p, int tid) {
+  constexpr int PH = PatchDim<HALO>::PH, NPIX = PatchDim<HALO>::NPIX, ITERS = PatchDim<HALO>::ITERS;
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[j][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  TileGeom g;
-  g.ph = ph; g.pw = pw;
-  g.oy = halo ? y0 - 1 : y0; g.ox = halo ? x0 - 1 : x0;
-  g.sy = gather ? 2 : 1; g.ay = 0; g.ax = 0;
-  g.lim_y = halo ? p.H + 1 : p.H; g.lim_x = halo ? p.W + 1 : p.W;
-  g.min_y = halo ? -1 : 0; g.min_x = halo ? -1 : 0;
-  g.hin = p.hin; g.win = p.win;
-
-  constexpr int KC = DD_LDS_ROW / (int)sizeof(T);  // channels per K-slice
-  const int nslices = (p.kchunks + 1) >> 1;
-  const int q = lane >> 4, li = lane & 15;
-
-  for (int s = 0; s < nslices; ++s) {
-    const int nch = min(2, p.kchunks - 2 * s);
-    __syncthreads();  // every wave is done with the previous slice's patch
-    if (halo) stage_pixels<T>(patch, X, img_base, p.ldx, p.cin, s * KC, nch * 4, g, in_relu, tid, 256);
-    for (int t = 0; t < p.taps; ++t) {
-      if (!halo) {
-        if (t > 0) __syncthreads();
-        if (gather) { g.ay = t >> 1; g.ax = t & 1; }
-        stage_pixels<T>(patch, X, img_base, p.ldx, p.cin, s * KC, nch * 4, g, in_relu, tid, 256);
-      }
-      char* wb = wbuf + (t & 1) * WB;
-      {  // weight slab of (tap t, slice s): NT*16 rows of 128 B
-        const int total = NT * 16 * 8;
-        for (int i = tid; i < total; i += 256) {
-          const int row = i >> 3, slot = i & 7;
-          if (slot >= nch * 4) continue;
-          const int ng = n0 + row;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (ng < p.n_pad)
-            v = *reinterpret_cast<const uint4*>(Wp + ((long)t * p.n_pad + ng) * p.k_pad + s * KC + slot * Elem<T>::PER16);
-          *reinterpret_cast<uint4*>(wb + lds_off(row, slot)) = v;
-        }
-      }
-      __syncthreads();
-      const int dy = halo ? t / 3 : 0, dx = halo ? t - dy * 3 : 0;
-      for (int c = 0; c < nch; ++c) {
-        const int slot = c * 4 + q;
-        uint4 bf[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pix = (wave * 4 + r + dy) * pw + li + dx;
-          bf[r] = *reinterpret_cast<const uint4*>(patch + lds_off(pix, slot));
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const uint4 af = *reinterpret_cast<const uint4*>(wb + lds_off(j * 16 + li, slot));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[j][r] = mma16<T>(af, bf[r], acc[j][r]);
-        }
-      }
-    }
+  for (int it = 0; it < ITERS; ++it) {
+    const int i = tid + it * 256;
+    const int pix = i >> 3, slot = i & 7;
+    const int py = pix / PH, px = pix - py * PH;
+    pl.yx[it] = pix < NPIX ? ((py << 8) | px) : -1;
+    pl.rel[it] = (py * p.win + px) * p.ldx;
+    pl.lds[it] = lds_off(pix, slot);
   }
+}
 
-  // ---------------------------------------------------------------- epilogue
-  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
-  const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
-  const T* __restrict__ M = reinterpret_cast<const T*>(p.mask);
-  const bool out_relu = (p.flags & DD_OUT_RELU) != 0, accum = (p.flags & DD_ACCUM) != 0;
-  const bool pixshuf = (p.flags & DD_PIXSHUF) != 0;
-  const int cout = pixshuf ? p.n / 4 : p.n;
-  const int ox = x0 + li;
+struct TileCoord { int b, y0, x0; };
+__device__ __forceinline__ TileCoord tile_coord(const ConvP& p, int tile) {
+  const int per_img = p.tiles_y * p.tiles_x;
+  TileCoord t;
+  t.b = tile / per_img;
+  const int rem = tile - t.b * per_img;
+  const int ty = rem / p.tiles_x;
+  t.y0 = ty * DD_TILE;
+  t.x0 = (rem - ty * p.tiles_x) * DD_TILE;
+  return t;
+}
+
+// Issue the global loads of one patch K-slice into registers.  Interior tiles (the whole patch inside the image, no gather):
+// one 64-bit add per vector.  Edge tiles / the 2x2 gather: per-vector bounds test selecting the zero page.
+template <typename T, bool HALO>
+__device__ __forceinline__ void patch_load(uint4 (&reg)[PatchDim<HALO>::ITERS], const PatchPlan<HALO>& pl, const T* __restrict__ X, const ConvP& p,
+                                           int tile, int slice, int tap, int nslots, int tid) {
+  constexpr int ITERS = PatchDim<HALO>::ITERS, PH = PatchDim<HALO>::PH;
+  constexpr int PER16 = Elem<T>::PER16, KC = DD_LDS_ROW / (int)sizeof(T);
+  const TileCoord tc = tile_coord(p, tile);
+  const int oy = tc.y0 - (HALO ? 1 : 0), ox = tc.x0 - (HALO ? 1 : 0);
+  const bool gather = (p.flags & DD_GATHER2X2) != 0;
+  const int slot = tid & 7;
+  const int ch = slice * KC + slot * PER16;
+  const bool ch_ok = slot < nslots && ch < p.cin;
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16);
+  const bool interior = !gather && oy >= 0 && ox >= 0 && oy + PH <= p.H && ox + PH <= p.W;
+  if (interior) {
+    const T* base = ch_ok ? X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch : zero;
+    const int mul = ch_ok ? 1 : 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int oy = y0 + wave * 4 + r;
-    if (oy >= p.H || ox >= p.W) continue;
+    for (int it = 0; it < ITERS; ++it) reg[it] = *reinterpret_cast<const uint4*>(base + (pl.yx[it] >= 0 ? pl.rel[it] * mul : 0));
+  } else {
+    const int sy = gather ? 2 : 1, ay = gather ? (tap >> 1) : 0, ax = gather ? (tap & 1) : 0;
+    const T* base = X + (long)tc.b * p.hin * p.win * p.ldx + ch;
+    const int ylo = HALO ? -1 : 0, yhi = p.H + (HALO ? 1 : 0), xhi = p.W + (HALO ? 1 : 0);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + q * 4;
-      if (n >= p.n) continue;
-      float v[4] = {acc[j][r][0], acc[j][r][1], acc[j][r][2], acc[j][r][3]};
-      if (p.bias) {
-        const int bi = pixshuf ? n % cout : n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (bi + e < p.nbias) v[e] += p.bias[bi + e];
-      }
-      long pix; int ch;
-      if (pixshuf) {
-        const int ab = n / cout; ch = n - ab * cout;
-        pix = ((long)b * p.hout + 2 * oy + (ab >> 1)) * p.wout + 2 * ox + (ab & 1);
-      } else {
-        ch = n;
-        pix = ((long)b * p.hout + oy) * p.wout + ox;
-      }
-      if (R) { float t[4]; load4<T>(R + pix * p.ldres + ch, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-      if (out_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      if (M) {
-        float t[4]; load4<T>(M + pix * p.ldmask + ch, t);
-        v[0] = t[0] > 0.f ? v[0] : 0.f; v[1] = t[1] > 0.f ? v[1] : 0.f; v[2] = t[2] > 0.f ? v[2] : 0.f; v[3] = t[3] > 0.f ? v[3] : 0.f;
-      }
-      T* dst = Y + pix * p.ldy + ch;
-      if (accum) { float t[4]; load4<T>(dst, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-      store4<T>(dst, v);
+    for (int it = 0; it < ITERS; ++it) {
+      const int yx = pl.yx[it];
+      const int ly = oy + (yx >> 8), lx = ox + (yx & 255);
+      const int gy = ly * sy + ay, gx = lx * sy + ax;
+      const bool ok = yx >= 0 && ch_ok && ly >= ylo && lx >= ylo && ly < yhi && lx < xhi && gy >= 0 && gx >= 0 && gy < p.hin && gx < p.win;
+      const T* ptr = ok ? base + ((long)gy * p.win + gx) * p.ldx : zero;
+      reg[it] = *reinterpret_cast<const uint4*>(ptr);
     }
   }
 }
 
+template <typename T, bool HALO>
+__device__ __forceinline__ void patch_store(char* lds, const uint4 (&reg)[PatchDim<HALO>::ITERS], const PatchPlan<HALO>& pl, bool in_relu) {
+#pragma unroll
+  for (int it = 0; it < PatchDim<HALO>::ITERS; ++it) {
+    uint4 v = reg[it];
+    if (in_relu) v = relu16<T>(v);
+    if (pl.yx[it] >= 0) *reinterpret_cast<uint4*>(lds + pl.lds[it]) = v;
+  }
+}
+
+// weight slab of one (tap, slice): NT*16 rows of 128 B
 template <typename T, int NT>
-int launch(const ConvP& p, hipStream_t stream) {
-  const int ph = (p.taps == 9) ? DD_TILE + 2 : DD_TILE;
-  const size_t lds = (size_t)ph * ph * DD_LDS_ROW + 2 * (size_t)NT * 16 * DD_LDS_ROW;
+__device__ __forceinline__ void slab_load(uint4 (&reg)[(NT + 1) / 2], const T* __restrict__ Wp, const ConvP& p, int n0, int tap, int slice, int nslots, int tid) {
+  constexpr int KC = DD_LDS_ROW / (int)sizeof(T);
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16);
+#pragma unroll
+  for (int it = 0; it < (NT + 1) / 2; ++it) {
+    const int i = tid + it * 256;
+    const int row = i >> 3, slot = i & 7;
+    const int ng = n0 + row;
+    const bool ok = row < NT * 16 && slot < nslots && ng < p.n_pad;
+    reg[it] = *reinterpret_cast<const uint4*>(ok ? Wp + ((long)tap * p.n_pad + ng) * p.k_pad + slice * KC + slot * Elem<T>::PER16 : zero);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void slab_store(char* lds, const uint4 (&reg)[(NT + 1) / 2], int tid) {
+#pragma unroll
+  for (int it = 0; it < (NT + 1) / 2; ++it) {
+    const int i = tid + it * 256;
+    const int row = i >> 3, slot = i & 7;
+    if (row < NT * 16) *reinterpret_cast<uint4*>(lds + lds_off(row, slot)) = reg[it];
+  }
+}
+
+#ifndef DD_SCHED
+#define DD_SCHED 2
+#endif
+
+// MFMA work of `NTAPS` consecutive taps on one staged patch: all fragment reads of step s+1 are issued before the MFMAs of
+// step s (double buffering in registers) and the interleave is PINNED with sched_group_barrier -- left alone, hipcc sinks
+// every weight-fragment ds_read right in front of its 4 MFMAs behind an s_waitcnt lgkmcnt(0) (measured: 29 vs 20 cycles/MFMA).
+template <typename T, int NT, int PH, int NTAPS, int NCH>
+__device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* patch, int pix_shift, const char* wslab0, int wslab_stride, int tap_first,
+                                          int wave, int q, int li) {
+  constexpr int STEPS = NTAPS * NCH;
+  uint4 bf[2][4], af[2][NT];
+  auto fetch = [&](int s, uint4 (&b)[4], uint4 (&a)[NT]) {
+    const int ti = s / NCH, c = s - ti * NCH;
+    const int tap = tap_first + ti;
+    const int dy = NTAPS == 9 ? tap / 3 : 0, dx = NTAPS == 9 ? tap - dy * 3 : 0;
+    const int slot = c * 4 + q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(patch + lds_off((wave * 4 + r + dy) * PH + li + dx + pix_shift, slot));
+    const char* wb = wslab0 + ti * wslab_stride;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const uint4*>(wb + lds_off(j * 16 + li, slot));
+  };
+  fetch(0, bf[0], af[0]);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    if (s + 1 < STEPS) fetch(s + 1, bf[(s + 1) & 1], af[(s + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][r] = mma16<T>(af[s & 1][j], bf[s & 1][r], acc[j][r]);
+#if DD_SCHED == 2
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int i = 0; i < 4 + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // 1 DS read of the next step
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (4 + NT), 0);     // MFMAs of this step
+      }
+    }
+#endif
+  }
+}
+
+template <typename T, int NT, bool HALO, bool RESIDENT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PH = PatchDim<HALO>::PH, PATCH_BYTES = PatchDim<HALO>::NPIX * DD_LDS_ROW;
+  constexpr int WB = NT * 16 * DD_LDS_ROW;    // bytes of one weight slab
+  constexpr int INNER = HALO ? 9 : 1;         // taps that reuse one staged patch
+  constexpr bool BF = sizeof(T) == 2;
+  char* patch = smem;
+  char* wbase = smem + PATCH_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.x % p.nblk, first = blockIdx.x / p.nblk, stride = gridDim.x / p.nblk;
+  const int n0 = nb * NT * 16;
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.wp);
+  const int nslices = (p.kchunks + 1) >> 1;
+  const int outer = HALO ? nslices : nslices * p.taps;   // units per tile
+  const int q = lane >> 4, li = lane & 15;
+  const bool in_relu = (p.flags & DD_IN_RELU) != 0;
+  if (first >= p.total_tiles) return;
+
+  if (RESIDENT) {   // every (tap, slice) slab of this channel block, once per workgroup
+    const int nslabs = p.taps * nslices;
+    for (int sidx = 0; sidx < nslabs; ++sidx) {
+      const int tap = sidx % p.taps, slice = sidx / p.taps;
+      const int nch = min(2, p.kchunks - 2 * slice);
+      uint4 wr[(NT + 1) / 2];
+      slab_load<T, NT>(wr, Wp, p, n0, tap, slice, nch * 4, tid);
+      slab_store<NT>(wbase + sidx * WB, wr, tid);
+    }
+  }
+
+  const bool pixshuf = (p.flags & DD_PIXSHUF) != 0;
+  const int cout = pixshuf ? p.n / 4 : p.n;
+  float biasr[NT][4];   // this lane's bias values (channels n0 + j*16 + q*4 + e): the accumulators START from them
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + j * 16 + q * 4 + e;
+      const int bi = pixshuf ? n % cout : n;
+      biasr[j][e] = (p.bias && n < p.n && bi < p.nbias) ? p.bias[bi] : 0.f;
+    }
+  // Coalesced-epilogue plan (bf16): the wave's 64 pixels x 64 channels go through an 8 KiB wave-private LDS region in chunks of
+  // 4 channel tiles; read-back vector `it` of this lane is pixel epix[it] (tile-local index), 8 channels starting at ech.
+  constexpr int ESLOTS = 8;
+  int e_lds[ESLOTS], e_pix[ESLOTS];
+  const int e_slot = lane & 7;
+  if (BF) {
+#pragma unroll
+    for (int it = 0; it < ESLOTS; ++it) {
+      const int pixl = (lane >> 3) + it * 8;                   // 0..63 within the wave's 4 rows
+      e_lds[it] = lds_off(pixl, e_slot);
+      const int tyl = wave * 4 + (pixl >> 4), txl = pixl & 15;
+      e_pix[it] = pixshuf ? (2 * tyl) * p.wout + 2 * txl : tyl * p.wout + txl;     // pixel offset from the tile origin (ab added per chunk)
+    }
+  }
+  PatchPlan<HALO> plan;
+  patch_plan<HALO>(plan, p, tid);
+#ifdef DD_STAGGER
+  // de-phase the workgroups: all CUs otherwise run load / MFMA / store phases in lockstep and HBM sees bursts
+  for (int i = 0; i < (int)(blockIdx.x % DD_STAGGER); ++i) __builtin_amdgcn_s_sleep(DD_STAGGER_SLEEP);
+#endif
+  f32x4_t acc[NT][4];
+  uint4 pre[PatchDim<HALO>::ITERS];
+  uint4 wreg[(NT + 1) / 2];
+  int tile = first, o = 0;
+  {
+    const int nch = min(2, p.kchunks);
+    patch_load<T, HALO>(pre, plan, X, p, tile, 0, 0, nch * 4, tid);
+    patch_store<T, HALO>(patch, pre, plan, in_relu);
+    if (!RESIDENT) slab_load<T, NT>(wreg, Wp, p, n0, 0, 0, nch * 4, tid);
+  }
+  __syncthreads();
+
+  while (tile < p.total_tiles) {
+    // this unit: outer step o of `tile`
+    const int slice = HALO ? o : o / p.taps, tap0 = HALO ? 0 : o % p.taps;
+    const int nch = min(2, p.kchunks - 2 * slice);
+    int no = o + 1, ntile = tile;
+    if (no == outer) { no = 0; ntile = tile + stride; }
+    const bool has_next = ntile < p.total_tiles;
+    const int nslice = HALO ? no : no / p.taps, ntap0 = HALO ? 0 : no % p.taps;
+    const int nnch = min(2, p.kchunks - 2 * nslice);
+    PHASE_T(t0);
+    if (has_next) patch_load<T, HALO>(pre, plan, X, p, ntile, nslice, ntap0, nnch * 4, tid);   // in flight during the MFMAs below
+    PHASE_T(t1);
+    if (o == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = f32x4_t{biasr[j][0], biasr[j][1], biasr[j][2], biasr[j][3]};
+    }
+
+    if (RESIDENT) {
+      const char* w0 = wbase + (slice * p.taps + tap0) * WB;
+      if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, w0, WB, tap0, wave, q, li);
+      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, w0, WB, tap0, wave, q, li);
+    } else {
+#pragma unroll 1
+      for (int ti = 0; ti < INNER; ++ti) {
+        const int tap = tap0 + ti;
+        char* wdst = wbase + (ti & 1) * WB;
+        slab_store<NT>(wdst, wreg, tid);
+        __syncthreads();
+        // prefetch the next slab (next tap of this unit, or the first tap of the next unit) while this tap computes
+        if (ti + 1 < INNER) slab_load<T, NT>(wreg, Wp, p, n0, tap + 1, slice, nch * 4, tid);
+        else if (has_next) slab_load<T, NT>(wreg, Wp, p, n0, ntap0, nslice, nnch * 4, tid);
+        const int dy = HALO ? ti / 3 : 0, dx = HALO ? ti - dy * 3 : 0;
+        if (nch == 2) mma_phase<T, NT, PH, 1, 2>(acc, patch, dy * PH + dx, wdst, 0, 0, wave, q, li);
+        else mma_phase<T, NT, PH, 1, 1>(acc, patch, dy * PH + dx, wdst, 0, 0, wave, q, li);
+      }
+    }
+    PHASE_T(t2);
+    __syncthreads();   // every wave is done reading the patch (and the streamed slabs)
+
+    if (o == outer - 1) {
+      // ---------------------------------------------------------------- epilogue of `tile`
+      const TileCoord tc = tile_coord(p, tile);
+      T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+      const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
+      const T* __restrict__ M = reinterpret_cast<const T*>(p.mask);
+      const bool out_relu = (p.flags & DD_OUT_RELU) != 0, accum = (p.flags & DD_ACCUM) != 0;
+      if constexpr (BF) {
+        // Transposed, fully coalesced epilogue: every global access is a 16-byte vector, 8 lanes = 128 contiguous bytes.
+        char* stage = patch + wave * (64 * DD_LDS_ROW);   // wave-private 8 KiB region of the (consumed) patch buffer
+        const bool interior = tc.y0 + DD_TILE <= p.H && tc.x0 + DD_TILE <= p.W;
+        const long tile_pix = pixshuf ? ((long)tc.b * p.hout + 2 * tc.y0) * p.wout + 2 * tc.x0 : ((long)tc.b * p.hout + tc.y0) * p.wout + tc.x0;
+#pragma unroll
+        for (int jb = 0; jb < NT; jb += 4) {
+          const int ntc = NT - jb < 4 ? NT - jb : 4;      // channel tiles in this chunk (compile-time after unrolling)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              if (jj >= ntc) continue;
+              const int j = jb + jj;
+              f32x4_t a = acc[j][r];
+              if (out_relu && !R) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f); }
+              uint2 pk;
+              pk.x = pack_bf16x2(a[0], a[1]);
+              pk.y = pack_bf16x2(a[2], a[3]);
+              *reinterpret_cast<uint2*>(stage + lds_off(r * 16 + li, jj * 2 + (q >> 1)) + (q & 1) * 8) = pk;
+            }
+          const int n = n0 + jb * 16 + e_slot * 8;        // first of this lane's 8 channels
+          const bool lane_ok = e_slot < ntc * 2 && n < p.n;
+          int ch = lane_ok ? n : 0; long abpix = 0;
+          if (pixshuf) { const int ab = ch / cout; ch = ch - ab * cout; abpix = (long)(ab >> 1) * p.wout + (ab & 1); }
+#pragma unroll
+          for (int half = 0; half < ESLOTS; half += 4) {
+            uint4 pv[4], mv[4], rv[4], av[4];
+            long pixv[4];
+            bool okv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {      // pass 1: every load of these 4 vectors in flight at once, all unconditional
+              const int it = half + k;
+              const int pixl = (lane >> 3) + it * 8;
+              okv[k] = lane_ok && (interior || (tc.y0 + wave * 4 + (pixl >> 4) < p.H && tc.x0 + (pixl & 15) < p.W));
+              pixv[k] = okv[k] ? tile_pix + abpix + e_pix[it] : tile_pix;    // the tile origin is always a valid pixel
+              pv[k] = *reinterpret_cast<const uint4*>(stage + e_lds[it]);
+              if (M) mv[k] = *reinterpret_cast<const uint4*>(M + pixv[k] * p.ldmask + ch);
+              if (R) rv[k] = *reinterpret_cast<const uint4*>(R + pixv[k] * p.ldres + ch);
+              if (accum) av[k] = *reinterpret_cast<const uint4*>(Y + pixv[k] * p.ldy + ch);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {      // pass 2: combine + predicated store
+              uint4 o4 = pv[k];
+              if (R) {
+                float v[8], t[8];
+                unpack8(o4, v); unpack8(rv[k], t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] += t[e]; if (out_relu) v[e] = fmaxf(v[e], 0.f); }
+                o4 = pack8(v);
+              }
+              if (M) o4 = mask_bf16x8(o4, mv[k]);
+              if (accum) {
+                float v[8], t[8];
+                unpack8(o4, v); unpack8(av[k], t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e];
+                o4 = pack8(v);
+              }
+              if (okv[k]) *reinterpret_cast<uint4*>(Y + pixv[k] * p.ldy + ch) = o4;
+            }
+          }
+        }
+      } else {
+        const int ox = tc.x0 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int oy = tc.y0 + wave * 4 + r;
+          if (oy >= p.H || ox >= p.W) continue;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + q * 4;
+            if (n >= p.n) continue;
+            float v[4] = {acc[j][r][0], acc[j][r][1], acc[j][r][2], acc[j][r][3]};
+            long pix; int ch;
+            if (pixshuf) {
+              const int ab = n / cout; ch = n - ab * cout;
+              pix = ((long)tc.b * p.hout + 2 * oy + (ab >> 1)) * p.wout + 2 * ox + (ab & 1);
+            } else {
+              ch = n;
+              pix = ((long)tc.b * p.hout + oy) * p.wout + ox;
+            }
+            if (R) { float t[4]; load4<T>(R + pix * p.ldres + ch, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            if (out_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (M) {
+              float t[4]; load4<T>(M + pix * p.ldmask + ch, t);
+              v[0] = t[0] > 0.f ? v[0] : 0.f; v[1] = t[1] > 0.f ? v[1] : 0.f; v[2] = t[2] > 0.f ? v[2] : 0.f; v[3] = t[3] > 0.f ? v[3] : 0.f;
+            }
+            T* dst = Y + pix * p.ldy + ch;
+            if (accum) { float t[4]; load4<T>(dst, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            store4<T>(dst, v);
+          }
+        }
+      }
+    }
+    PHASE_T(t3);
+    if (has_next) {
+      if (BF && o == outer - 1) __syncthreads();   // the epilogue's staging reads are done before the patch is overwritten
+      patch_store<T, HALO>(patch, pre, plan, in_relu);
+    }
+    PHASE_T(t4);
+    __syncthreads();   // the next unit's patch is complete
+    PHASE_T(t5);
+    PHASE_ADD(0, t0, t1); PHASE_ADD(1, t1, t2); PHASE_ADD(2, t2, t3); PHASE_ADD(3, t3, t4); PHASE_ADD(4, t4, t5);
+    if (blockIdx.x == 0 && tid == 0) { PHASE_ADD(5, 0ull, 1ull); }
+    tile = ntile;
+    o = no;
+  }
+}
+
+int g_num_cus = 0;
+
+template <typename T, int NT, bool HALO, bool RESIDENT>
+int launch(const ConvP& p, int nslabs, hipStream_t stream) {
+  const size_t patch = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW;
+  const size_t wb = (size_t)NT * 16 * DD_LDS_ROW;
+  const size_t lds = patch + (RESIDENT ? (size_t)nslabs * wb : 2 * wb);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, NT, HALO, RESIDENT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const long blocks = (long)p.B * p.tiles_y * p.tiles_x * p.nblk;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NT>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  if (g_num_cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
+  }
+  const int per_cu = (int)((160 * 1024) / lds) >= 2 ? 2 : 1;   // two resident workgroups overlap each other's memory phases
+  long wgs = (long)g_num_cus * per_cu;
+  wgs = wgs / p.nblk * p.nblk;                              // a multiple of the channel-block count
+  if (wgs < p.nblk) wgs = p.nblk;
+  const long need = (long)p.total_tiles * p.nblk;
+  if (wgs > need) wgs = need;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NT, HALO, RESIDENT>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
+}
+
+static size_t lds_budget() {   // LDS a workgroup may use when deciding weight residency (DD_CONV_RESIDENT_BUDGET_KB=79 => 2 workgroups/CU)
+  static size_t v = 0;
+  if (!v) { const char* e = getenv("DD_CONV_RESIDENT_BUDGET_KB"); v = (size_t)(e ? atoi(e) : 158) * 1024; }
+  return v;
+}
+#define LDS_BUDGET lds_budget()
+
+template <typename T, int NT>
+int launch_nt(const ConvP& p, hipStream_t stream) {
+  const bool halo = p.taps == 9;
+  const int nslices = (p.kchunks + 1) / 2;
+  const int nslabs = p.taps * nslices;
+  const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
+  const bool resident = patch + (size_t)nslabs * NT * 16 * DD_LDS_ROW <= LDS_BUDGET;
+  if (halo) return resident ? launch<T, NT, true, true>(p, nslabs, stream) : launch<T, NT, true, false>(p, nslabs, stream);
+  return resident ? launch<T, NT, false, true>(p, nslabs, stream) : launch<T, NT, false, false>(p, nslabs, stream);
+}
+
+// Channel-block width policy.  DD_CONV_POLICY=wide keeps the widest block (fewest patch re-reads, best MFMA:LDS ratio);
+// the default prefers a block narrow enough for its weights to stay resident in LDS, but never narrower than min_resident_nt.
+static int conv_policy_min_resident_nt() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DD_CONV_MIN_RESIDENT_NT");
+    v = e ? atoi(e) : 2;
+    const char* w = getenv("DD_CONV_POLICY");
+    if (w && strcmp(w, "wide") == 0) v = 1000;
+  }
+  return v;
 }
 
 template <typename T>
 int dispatch(ConvP& p, hipStream_t stream) {
   const int tiles_n = p.n_pad / 16;
-  const long spatial = (long)p.B * p.tiles_y * p.tiles_x;
-  static const int cand[] = {8, 6, 4, 3, 2, 1};
-  int nt = 1;
-  for (int c : cand) if (tiles_n % c == 0) { nt = c; break; }
-  // keep >= 2 workgroups per CU in flight when the pixel grid is small
-  while (nt > 2 && nt % 2 == 0 && spatial * (tiles_n / nt) < 512) nt /= 2;
+  static const int allowed[] = {8, 6, 4, 2, 1};
+  int cands[5], nc = 0;
+  for (int c : allowed) if (tiles_n % c == 0) cands[nc++] = c;
+  const bool halo = p.taps == 9;
+  const int nslabs = p.taps * ((p.kchunks + 1) / 2);
+  const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
+  int pick = 0;   // widest
+  for (int i = 0; i < nc; ++i)
+    if (cands[i] >= conv_policy_min_resident_nt() && patch + (size_t)nslabs * cands[i] * 16 * DD_LDS_ROW <= LDS_BUDGET) { pick = i; break; }
+  // keep every CU busy when the pixel grid is small
+  while (pick + 1 < nc && cands[pick] > 2 && (long)p.total_tiles * (tiles_n / cands[pick]) < 256) ++pick;
+  const int nt = cands[pick];
   p.nblk = tiles_n / nt;
   switch (nt) {
-    case 8: return launch<T, 8>(p, stream);
-    case 6: return launch<T, 6>(p, stream);
-    case 4: return launch<T, 4>(p, stream);
-    case 3: return launch<T, 3>(p, stream);
-    case 2: return launch<T, 2>(p, stream);
-    default: return launch<T, 1>(p, stream);
+    case 8: return launch_nt<T, 8>(p, stream);
+    case 6: return launch_nt<T, 6>(p, stream);
+    case 4: return launch_nt<T, 4>(p, stream);
+    case 2: return launch_nt<T, 2>(p, stream);
+    default: return launch_nt<T, 1>(p, stream);
   }
 }
 
@@ -213,6 +547,7 @@ extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   p.ldx = a->ldx; p.cin = a->cin; p.k_pad = a->k_pad; p.n_pad = a->n_pad; p.ldres = a->ldres; p.ldmask = a->ldmask;
   p.ldy = a->ldy; p.n = a->n; p.B = a->B; p.H = a->H; p.W = a->W; p.taps = a->taps; p.flags = a->flags; p.nbias = a->bias ? a->nbias : 0;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE); p.nblk = 1;
+  p.total_tiles = a->B * p.tiles_x * p.tiles_y;
   p.kchunks = a->k_pad * esz / 64;
   p.hin = gather ? 2 * a->H : a->H; p.win = gather ? 2 * a->W : a->W;
   p.hout = pixshuf ? 2 * a->H : a->H; p.wout = pixshuf ? 2 * a->W : a->W;
