@@ -16,7 +16,7 @@ MAX_FEATURES, MAX_COMBINED = 32, 8
 
 # every symbol include/dd_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    "dd_version", "dd_last_error", "dd_pack_weights", "dd_conv_igemm", "dd_conv_wgrad", "dd_colsum",
+    "dd_version", "dd_last_error", "dd_pack_weights", "dd_pack_weights_batched", "dd_conv_igemm", "dd_conv_wgrad", "dd_colsum",
     "dd_maxpool_fwd", "dd_maxpool_bwd", "dd_avgpool", "dd_prepare_feature", "dd_gather_input",
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
@@ -38,9 +38,14 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [("p", C.c_void_p), ("ldp", C.c_int), ("m", C.c_int),
                 ("q", C.c_void_p), ("ldq", C.c_int), ("n", C.c_int),
-                ("out", C.c_void_p),
+                ("out", C.c_void_p), ("bias_out", C.c_void_p), ("bias_mode", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("taps", C.c_int), ("flags", C.c_int), ("dtype", C.c_int), ("ksplit", C.c_int)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("taps", C.c_int), ("n", C.c_int), ("k", C.c_int), ("n_pad", C.c_int),
+                ("k_pad", C.c_int), ("tap_flip", C.c_int), ("s_tap", C.c_long), ("s_n", C.c_long), ("s_k", C.c_long)]
 
 
 class FeatureParams(C.Structure):
@@ -101,6 +106,7 @@ def load():
         getattr(lib, s).restype = C.c_int
     vp, i, l, f = C.c_void_p, C.c_int, C.c_long, C.c_float
     lib.dd_pack_weights.argtypes = [vp, vp, i, i, i, i, i, i, l, l, l, i, vp]
+    lib.dd_pack_weights_batched.argtypes = [vp, i, i, vp]
     lib.dd_conv_igemm.argtypes = [C.POINTER(ConvArgs), vp]
     lib.dd_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
     lib.dd_colsum.argtypes = [vp, i, i, l, vp, i, vp]

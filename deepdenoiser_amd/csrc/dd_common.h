@@ -128,38 +128,9 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = 
 // quarter-wave) then hit 16 distinct 16-byte bank groups per ds_read_b128 service group (conflict-free for any base row).
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * DD_LDS_ROW + ((slot ^ (row & 7)) << 4); }
 
-// Geometry of the pixel tile a workgroup stages for one K-slice.
-struct TileGeom {
-  int ph, pw;      // staged pixels (rows, cols): 18x18 with halo, 16x16 without
-  int oy, ox;      // image coordinate of staged pixel (0,0) before the stride/offset mapping
-  int sy;          // 1, or 2 for the 2x2/s2 gather
-  int ay, ax;      // additive offset after the stride (the (a,b) tap of the gather)
-  int lim_y, lim_x;// validity limits of (oy+py, ox+px) (the GEMM-row pixel grid)
-  int min_y, min_x;// lower validity limits (-1 with halo => image bounds check only)
-  int hin, win;    // input image size
-};
-
-// Stage one K-slice of a pixel tile: global NHWC -> LDS [pixel][128 B], zero-filling out-of-image pixels and channels >= cin.
-template <typename T>
-__device__ __forceinline__ void stage_pixels(char* lds, const T* __restrict__ x, long img_base, int ldx, int cin, int ch0,
-                                             int nslots, const TileGeom& g, bool in_relu, int tid, int nthreads) {
-  constexpr int PER16 = Elem<T>::PER16;
-  const int total = g.ph * g.pw * 8;
-  for (int i = tid; i < total; i += nthreads) {
-    const int pix = i >> 3, slot = i & 7;
-    if (slot >= nslots) continue;
-    const int py = pix / g.pw, px = pix - py * g.pw;
-    const int ly = g.oy + py, lx = g.ox + px;
-    const int gy = ly * g.sy + g.ay, gx = lx * g.sy + g.ax;
-    const int ch = ch0 + slot * PER16;
-    // unconditional load from a clamped address + select (a branch per vector would serialise the loads on vmcnt(0))
-    const bool ok = ly >= g.min_y && lx >= g.min_x && ly < g.lim_y && lx < g.lim_x && gy >= 0 && gx >= 0 && gy < g.hin && gx < g.win && ch < cin;
-    uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? (img_base + (long)gy * g.win + gx) * ldx + ch : 0));
-    if (in_relu) v = relu16<T>(v);
-    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-    *reinterpret_cast<uint4*>(lds + lds_off(pix, slot)) = v;
-  }
-}
+// 16 bytes of zeros: invalid vectors (outside the image / channels >= cin) are read from here, so every tile load is
+// unconditional and needs no select afterwards (one copy per translation unit).
+static __device__ uint4 dd_zero16_v = {0u, 0u, 0u, 0u};
 
 // MFMA on one 16-byte k-group: bf16 -> one 16x16x32 MFMA; f32 -> four exact-f32 16x16x4 MFMAs (k permuted
 // consistently for both operands, which leaves the sum unchanged).

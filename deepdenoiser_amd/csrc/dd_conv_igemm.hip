@@ -22,22 +22,20 @@
 #include "dd_common.h"
 
 #ifdef DD_PROFILE_PHASES
-__device__ unsigned long long dd_phase_cycles[8];
+__device__ unsigned long long dd_phase_cycles[16];
 #define PHASE_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PHASE_ADD(i, a, b) if (blockIdx.x == 0 && tid == 0) dd_phase_cycles[i] += (b) - (a)
+#define PHASE_ADD_T(i, a, b, t) if (blockIdx.x == 0 && tid == (t)) dd_phase_cycles[i] += (b) - (a)
 extern "C" int dd_debug_phases(unsigned long long* out8, int reset) {
-  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(dd_phase_cycles), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_phase_cycles), z, sizeof(z)); }
+  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(dd_phase_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_phase_cycles), z, sizeof(z)); }
   return 0;
 }
 #else
 #define PHASE_T(var)
 #define PHASE_ADD(i, a, b)
+#define PHASE_ADD_T(i, a, b, t)
 #endif
-
-// 16 bytes of zeros: invalid vectors (outside the image / channels >= cin) are read from here, so every load of a patch is
-// unconditional and needs no select afterwards.
-__device__ uint4 dd_zero16 = {0u, 0u, 0u, 0u};
 
 namespace {
 
@@ -106,7 +104,7 @@ __device__ __forceinline__ void patch_load(uint4 (&reg)[PatchDim<HALO>::ITERS], 
   const int slot = tid & 7;
   const int ch = slice * KC + slot * PER16;
   const bool ch_ok = slot < nslots && ch < p.cin;
-  const T* zero = reinterpret_cast<const T*>(&dd_zero16);
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
   const bool interior = !gather && oy >= 0 && ox >= 0 && oy + PH <= p.H && ox + PH <= p.W;
   if (interior) {
     const T* base = ch_ok ? X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch : zero;
@@ -143,7 +141,7 @@ __device__ __forceinline__ void patch_store(char* lds, const uint4 (&reg)[PatchD
 template <typename T, int NT>
 __device__ __forceinline__ void slab_load(uint4 (&reg)[(NT + 1) / 2], const T* __restrict__ Wp, const ConvP& p, int n0, int tap, int slice, int nslots, int tid) {
   constexpr int KC = DD_LDS_ROW / (int)sizeof(T);
-  const T* zero = reinterpret_cast<const T*>(&dd_zero16);
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
 #pragma unroll
   for (int it = 0; it < (NT + 1) / 2; ++it) {
     const int i = tid + it * 256;
@@ -439,6 +437,201 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant (bf16, resident weights, NT <= 4): 8 waves per workgroup, 2 per SIMD.
+//   waves 0-3 (MFMA role): ds_read + MFMA only; at the end of a tile they park the bf16 result in a 32 KiB LDS stage.
+//   waves 4-7 (I/O role) : issue the global loads of the NEXT unit's patch, drain the PREVIOUS tile's stage to global memory
+//                          with coalesced 16-byte vectors (+ mask / residual / accumulate), then write the patch to LDS.
+// A wave that stalls on memory cannot issue MFMAs, and HBM writes run at only ~3.2 TB/s (tools/ubench/mem_ubench.hip): with the
+// roles split, the SIMD's scheduler overlaps the I/O waves' stalls with the MFMA waves' matrix work.  Two barriers per unit.
+template <int NT, bool HALO>
+__global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PH = PatchDim<HALO>::PH, PATCH_BYTES = PatchDim<HALO>::NPIX * DD_LDS_ROW;
+  constexpr int STAGE_BYTES = DD_TILE * DD_TILE * DD_LDS_ROW;
+  constexpr int WB = NT * 16 * DD_LDS_ROW;
+  constexpr int INNER = HALO ? 9 : 1;
+  char* patch = smem;
+  char* stage_all = smem + PATCH_BYTES;
+  char* wbase = smem + PATCH_BYTES + STAGE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool io = wave >= 4;
+  const int w4 = wave & 3, t256 = tid & 255;
+  const int nb = blockIdx.x % p.nblk, first = blockIdx.x / p.nblk, stride = gridDim.x / p.nblk;
+  const int n0 = nb * NT * 16;
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.wp);
+  const int nslices = (p.kchunks + 1) >> 1;
+  const int outer = HALO ? nslices : nslices * p.taps;
+  const int q = lane >> 4, li = lane & 15;
+  const bool in_relu = (p.flags & DD_IN_RELU) != 0;
+  const bool pixshuf = (p.flags & DD_PIXSHUF) != 0;
+  const int cout = pixshuf ? p.n / 4 : p.n;
+  const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
+  const T* __restrict__ M = reinterpret_cast<const T*>(p.mask);
+  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+  const bool out_relu = (p.flags & DD_OUT_RELU) != 0, accum = (p.flags & DD_ACCUM) != 0;
+  if (first >= p.total_tiles) return;
+  char* stage = stage_all + w4 * (64 * DD_LDS_ROW);   // MFMA wave w4 writes it, I/O wave w4 drains it
+
+  PatchPlan<HALO> plan;
+  uint4 pre[PatchDim<HALO>::ITERS];
+  if (io) {
+    const int nslabs = p.taps * nslices;
+    for (int sidx = 0; sidx < nslabs; ++sidx) {
+      const int tap = sidx % p.taps, slice = sidx / p.taps;
+      const int nch = min(2, p.kchunks - 2 * slice);
+      uint4 wr[(NT + 1) / 2];
+      slab_load<T, NT>(wr, Wp, p, n0, tap, slice, nch * 4, t256);
+      slab_store<NT>(wbase + sidx * WB, wr, t256);
+    }
+    patch_plan<HALO>(plan, p, t256);
+    patch_load<T, HALO>(pre, plan, X, p, first, 0, 0, min(2, p.kchunks) * 4, t256);
+    patch_store<T, HALO>(patch, pre, plan, in_relu);
+  }
+  __syncthreads();
+
+  int tile = first, o = 0;
+  if (!io) {
+    // ------------------------------------------------------------------ MFMA role
+    float biasr[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + j * 16 + q * 4 + e;
+        const int bi = pixshuf ? n % cout : n;
+        biasr[j][e] = (p.bias && n < p.n && bi < p.nbias) ? p.bias[bi] : 0.f;
+      }
+    f32x4_t acc[NT][4];
+    while (tile < p.total_tiles) {
+      const int slice = HALO ? o : o / p.taps, tap0 = HALO ? 0 : o % p.taps;
+      const int nch = min(2, p.kchunks - 2 * slice);
+      int no = o + 1, ntile = tile;
+      if (no == outer) { no = 0; ntile = tile + stride; }
+      if (o == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[j][r] = f32x4_t{biasr[j][0], biasr[j][1], biasr[j][2], biasr[j][3]};
+      }
+      const char* w0 = wbase + (slice * p.taps + tap0) * WB;
+      PHASE_T(m0);
+      if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, w0, WB, tap0, w4, q, li);
+      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, w0, WB, tap0, w4, q, li);
+      PHASE_T(m1);
+      __syncthreads();   // bar1: patch consumed by every MFMA wave; stage drained by the I/O waves
+      PHASE_T(m2);
+      if (o == outer - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            f32x4_t a = acc[j][r];
+            if (out_relu && !R) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f); }
+            uint2 pk;
+            pk.x = pack_bf16x2(a[0], a[1]);
+            pk.y = pack_bf16x2(a[2], a[3]);
+            *reinterpret_cast<uint2*>(stage + lds_off(r * 16 + li, j * 2 + (q >> 1)) + (q & 1) * 8) = pk;
+          }
+      }
+      PHASE_T(m3);
+      __syncthreads();   // bar2: stage full; next patch complete
+      PHASE_T(m4);
+      PHASE_ADD_T(0, m0, m1, 0); PHASE_ADD_T(1, m1, m2, 0); PHASE_ADD_T(2, m2, m3, 0); PHASE_ADD_T(3, m3, m4, 0); PHASE_ADD_T(5, 0ull, 1ull, 0);
+      tile = ntile;
+      o = no;
+    }
+  } else {
+    // ------------------------------------------------------------------ I/O role
+    constexpr int ESLOTS = 8;
+    int e_lds[ESLOTS], e_pix[ESLOTS];
+    const int e_slot = lane & 7;
+#pragma unroll
+    for (int it = 0; it < ESLOTS; ++it) {
+      const int pixl = (lane >> 3) + it * 8;
+      e_lds[it] = lds_off(pixl, e_slot);
+      const int tyl = w4 * 4 + (pixl >> 4), txl = pixl & 15;
+      e_pix[it] = pixshuf ? (2 * tyl) * p.wout + 2 * txl : tyl * p.wout + txl;
+    }
+    const int n = n0 + e_slot * 8;
+    const bool lane_ok = e_slot < NT * 2 && n < p.n;
+    int ch = lane_ok ? n : 0; long abpix = 0;
+    if (pixshuf) { const int ab = ch / cout; ch = ch - ab * cout; abpix = (long)(ab >> 1) * p.wout + (ab & 1); }
+
+    auto drain = [&](int dtile) {
+      const TileCoord tc = tile_coord(p, dtile);
+      const bool interior = tc.y0 + DD_TILE <= p.H && tc.x0 + DD_TILE <= p.W;
+      const long tile_pix = pixshuf ? ((long)tc.b * p.hout + 2 * tc.y0) * p.wout + 2 * tc.x0 : ((long)tc.b * p.hout + tc.y0) * p.wout + tc.x0;
+#pragma unroll
+      for (int half = 0; half < ESLOTS; half += 4) {
+        uint4 pv[4], mv[4], rv[4], av[4];
+        long pixv[4];
+        bool okv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int it = half + k;
+          const int pixl = (lane >> 3) + it * 8;
+          okv[k] = lane_ok && (interior || (tc.y0 + w4 * 4 + (pixl >> 4) < p.H && tc.x0 + (pixl & 15) < p.W));
+          pixv[k] = okv[k] ? tile_pix + abpix + e_pix[it] : tile_pix;
+          pv[k] = *reinterpret_cast<const uint4*>(stage + e_lds[it]);
+          if (M) mv[k] = *reinterpret_cast<const uint4*>(M + pixv[k] * p.ldmask + ch);
+          if (R) rv[k] = *reinterpret_cast<const uint4*>(R + pixv[k] * p.ldres + ch);
+          if (accum) av[k] = *reinterpret_cast<const uint4*>(Y + pixv[k] * p.ldy + ch);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint4 o4 = pv[k];
+          if (R) {
+            float v[8], t[8];
+            unpack8(o4, v); unpack8(rv[k], t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] += t[e]; if (out_relu) v[e] = fmaxf(v[e], 0.f); }
+            o4 = pack8(v);
+          }
+          if (M) o4 = mask_bf16x8(o4, mv[k]);
+          if (accum) {
+            float v[8], t[8];
+            unpack8(o4, v); unpack8(av[k], t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+            o4 = pack8(v);
+          }
+          if (okv[k]) *reinterpret_cast<uint4*>(Y + pixv[k] * p.ldy + ch) = o4;
+        }
+      }
+    };
+
+    int pending = -1;
+    while (tile < p.total_tiles) {
+      int no = o + 1, ntile = tile;
+      if (no == outer) { no = 0; ntile = tile + stride; }
+      const bool has_next = ntile < p.total_tiles;
+      const int nslice = HALO ? no : no / p.taps, ntap0 = HALO ? 0 : no % p.taps;
+      const int nnch = min(2, p.kchunks - 2 * nslice);
+      PHASE_T(i0);
+      if (has_next) patch_load<T, HALO>(pre, plan, X, p, ntile, nslice, ntap0, nnch * 4, t256);
+      PHASE_T(i1);
+      if (pending >= 0) { drain(pending); pending = -1; }
+      PHASE_T(i2);
+      __syncthreads();   // bar1
+      PHASE_T(i3);
+      if (has_next) patch_store<T, HALO>(patch, pre, plan, in_relu);
+      PHASE_T(i4);
+      __syncthreads();   // bar2
+      PHASE_T(i5);
+      PHASE_ADD_T(8, i0, i1, 256); PHASE_ADD_T(9, i1, i2, 256); PHASE_ADD_T(10, i2, i3, 256); PHASE_ADD_T(11, i3, i4, 256); PHASE_ADD_T(12, i4, i5, 256);
+      if (o == outer - 1) pending = tile;
+      tile = ntile;
+      o = no;
+    }
+    if (pending >= 0) drain(pending);
+  }
+}
+
 int g_num_cus = 0;
 
 template <typename T, int NT, bool HALO, bool RESIDENT>
@@ -467,6 +660,35 @@ int launch(const ConvP& p, int nslabs, hipStream_t stream) {
   return DD_OK;
 }
 
+template <int NT, bool HALO>
+int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
+  const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + (size_t)nslabs * NT * 16 * DD_LDS_ROW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<NT, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (g_num_cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
+  }
+  long wgs = (long)g_num_cus;
+  wgs = wgs / p.nblk * p.nblk;
+  if (wgs < p.nblk) wgs = p.nblk;
+  const long need = (long)p.total_tiles * p.nblk;
+  if (wgs > need) wgs = need;
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<NT, HALO>), dim3((unsigned)wgs), dim3(512), lds, stream, p);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+static bool ws_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DD_CONV_WS"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 static size_t lds_budget() {   // LDS a workgroup may use when deciding weight residency (DD_CONV_RESIDENT_BUDGET_KB=79 => 2 workgroups/CU)
   static size_t v = 0;
   if (!v) { const char* e = getenv("DD_CONV_RESIDENT_BUDGET_KB"); v = (size_t)(e ? atoi(e) : 158) * 1024; }
@@ -481,6 +703,10 @@ int launch_nt(const ConvP& p, hipStream_t stream) {
   const int nslabs = p.taps * nslices;
   const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
   const bool resident = patch + (size_t)nslabs * NT * 16 * DD_LDS_ROW <= LDS_BUDGET;
+  if constexpr (sizeof(T) == 2 && NT <= 4) {
+    const size_t ws_lds = patch + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + (size_t)nslabs * NT * 16 * DD_LDS_ROW;
+    if (ws_enabled() && ws_lds <= 160 * 1024) return halo ? launch_ws<NT, true>(p, nslabs, stream) : launch_ws<NT, false>(p, nslabs, stream);
+  }
   if (halo) return resident ? launch<T, NT, true, true>(p, nslabs, stream) : launch<T, NT, true, false>(p, nslabs, stream);
   return resident ? launch<T, NT, false, true>(p, nslabs, stream) : launch<T, NT, false, false>(p, nslabs, stream);
 }
@@ -509,7 +735,8 @@ int dispatch(ConvP& p, hipStream_t stream) {
   const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
   int pick = 0;   // widest
   for (int i = 0; i < nc; ++i)
-    if (cands[i] >= conv_policy_min_resident_nt() && patch + (size_t)nslabs * cands[i] * 16 * DD_LDS_ROW <= LDS_BUDGET) { pick = i; break; }
+    if (cands[i] >= conv_policy_min_resident_nt() &&
+        patch + (sizeof(T) == 2 && cands[i] <= 4 && ws_enabled() ? (size_t)DD_TILE * DD_TILE * DD_LDS_ROW : 0) + (size_t)nslabs * cands[i] * 16 * DD_LDS_ROW <= LDS_BUDGET + 2048) { pick = i; break; }
   // keep every CU busy when the pixel grid is small
   while (pick + 1 < nc && cands[pick] > 2 && (long)p.total_tiles * (tiles_n / cands[pick]) < 256) ++pick;
   const int nt = cands[pick];

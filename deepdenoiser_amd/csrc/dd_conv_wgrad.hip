@@ -1,35 +1,104 @@
-// Weight-gradient GEMM on CDNA4 MFMA.
+// Weight-gradient GEMM on CDNA4 MFMA (+ fused bias gradient).
 //
 //   out[t][m][n] += sum_{b, pixel p}  in(P)[b, map_t(p), m] * Q[b, p, n]          (fp32 atomics into the gradient arena)
 //
 // conv2d            : P = layer input x (3x3: halo patch, 1x1: same pixel), Q = pre-activation output gradient,
-//                     out = dKernel in TF HWIO layout [kh*kw][C_in][C_out].
+//                     out = dKernel in TF HWIO layout [kh*kw][C_in][C_out];  bias gradient = column sums of Q.
 // conv2d_transpose  : P = output gradient on the fine grid, map_t(p) = 2p+(a,b) (DD_GATHER2X2), Q = layer input,
-//                     out = dKernel in TF layout [a*2+b][C_out][C_in].
-// Replaces the TF-autodiff filter gradients behind tf.train.AdamOptimizer.minimize (reference
+//                     out = dKernel in TF layout [a*2+b][C_out][C_in];       bias gradient = column sums of P.
+// Replaces the TF-autodiff filter / bias gradients behind tf.train.AdamOptimizer.minimize (reference
 // TensorFlow/Training.py:701-702) for every conv in UNet.py / Tiramisu.py / Architecture.py:238-243 / MultiScalePrediction.py.
 //
 // Both operands are reduction-major in memory (NHWC: the pixel index is the GEMM K dimension), i.e. "transposed" with
 // respect to what an MFMA fragment wants (8 consecutive k per lane).  bf16 path: the NHWC tiles stay as they are in
 // LDS ([pixel][channel], 128-byte rows, slot-swizzled) and fragments are fetched with the gfx950 transpose read
-// ds_read_b64_tr_b16 (a 16-lane group reads a [4 pixels][16 channels] block, each lane receives one channel's 4 pixels);
-// a tap shift is a whole-row shift in that image, so the 3x3 halo patch is staged once and reused by the 9 taps.
-// f32 path: exact-f32 MFMA 16x16x4, one element per lane straight from the same image (ds_read_b32).
+// ds_read_b64_tr_b16 (a 16-lane group reads a [4 pixels][16 channels] block, each lane receives one channel's 4 pixels;
+// pinned by tests/test_gpu_ops.py::test_tr16_probe); a tap shift is a whole-row shift in that image, so the 3x3 halo
+// patch is staged once and reused by the 9 taps.  f32 path: exact-f32 MFMA 16x16x4, one element per lane (ds_read_b32).
 // A workgroup owns one (m-slice, n-slice) of 128 B worth of channels each, ALL taps, and a strided subset of the
 // 16x16 pixel tiles (split-K); partial results are added with one fp32 atomic per element at the end.
+// The bias gradient costs no extra pass over the gradient tensor: every thread sums the vectors it stages anyway.
+// All global loads are unconditional (invalid vectors read a zero page): a branch per vector serialises them.
+#include <stdlib.h>
+
 #include "dd_common.h"
 
 namespace {
 
 struct WgradP {
-  const void* p; const void* q; float* out;
+  const void* p; const void* q; float* out; float* bias_out;
   int ldp, m, ldq, n, mv, nv;   // mv/nv: staged (16-byte rounded) channel counts
-  int B, H, W, taps, flags;
+  int B, H, W, taps, flags, bias_mode;
   int tiles_x, tiles_y, ksplit, mslices, nslices;
   int hin, win;
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+template <int PH> struct TilePlan {
+  static constexpr int NPIX = PH * PH;
+  static constexpr int ITERS = (NPIX * 8 + 255) / 256;
+  int yx[ITERS];    // (py << 8) | px or -1
+  int lds[ITERS];
+};
+template <int PH>
+__device__ __forceinline__ void tile_plan(TilePlan<PH>& pl, int tid) {
+#pragma unroll
+  for (int it = 0; it < TilePlan<PH>::ITERS; ++it) {
+    const int i = tid + it * 256;
+    const int pix = i >> 3, slot = i & 7;
+    const int py = pix / PH, px = pix - py * PH;
+    pl.yx[it] = pix < TilePlan<PH>::NPIX ? ((py << 8) | px) : -1;
+    pl.lds[it] = lds_off(pix, slot);
+  }
+}
+
+// global -> registers for one K-slice of a pixel tile; (oy,ox) = image coordinate of tile pixel (0,0) on the GEMM-row grid
+template <typename T, int PH>
+__device__ __forceinline__ void tile_load(uint4 (&reg)[TilePlan<PH>::ITERS], const TilePlan<PH>& pl, const T* __restrict__ X, long img_base, int ld, int cvalid,
+                                          int ch0, int oy, int ox, int H, int W, int halo, int sy, int ay, int ax, int hin, int win, int tid) {
+  constexpr int PER16 = Elem<T>::PER16;
+  const int ch = ch0 + (tid & 7) * PER16;
+  const bool ch_ok = ch < cvalid;
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
+  const T* base = X + img_base * ld + ch;
+#pragma unroll
+  for (int it = 0; it < TilePlan<PH>::ITERS; ++it) {
+    const int yx = pl.yx[it];
+    const int ly = oy + (yx >> 8), lx = ox + (yx & 255);
+    const int gy = ly * sy + ay, gx = lx * sy + ax;
+    const bool ok = yx >= 0 && ch_ok && ly >= -halo && lx >= -halo && ly < H + halo && lx < W + halo && gy >= 0 && gx >= 0 && gy < hin && gx < win;
+    reg[it] = *reinterpret_cast<const uint4*>(ok ? base + ((long)gy * win + gx) * ld : zero);
+  }
+}
+template <typename T, int PH>
+__device__ __forceinline__ void tile_store(char* lds, const uint4 (&reg)[TilePlan<PH>::ITERS], const TilePlan<PH>& pl, bool in_relu) {
+#pragma unroll
+  for (int it = 0; it < TilePlan<PH>::ITERS; ++it) {
+    uint4 v = reg[it];
+    if (in_relu) v = relu16<T>(v);
+    if (pl.yx[it] >= 0) *reinterpret_cast<uint4*>(lds + pl.lds[it]) = v;
+  }
+}
+// per-thread running column sums of the staged vectors (this thread always covers the same 16-byte channel group)
+template <typename T, int PH>
+__device__ __forceinline__ void bias_accumulate(float (&bsum)[8], const uint4 (&reg)[TilePlan<PH>::ITERS], const TilePlan<PH>& pl, bool interior_only) {
+#pragma unroll
+  for (int it = 0; it < TilePlan<PH>::ITERS; ++it) {
+    const int yx = pl.yx[it];
+    const int py = yx >> 8, px = yx & 255;
+    const bool use = yx >= 0 && (!interior_only || (py >= 1 && py <= DD_TILE && px >= 1 && px <= DD_TILE));
+    if (sizeof(T) == 2) {
+      float v[8];
+      unpack8(reg[it], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum[e] += use ? v[e] : 0.f;
+    } else {
+      bsum[0] += use ? __uint_as_float(reg[it].x) : 0.f; bsum[1] += use ? __uint_as_float(reg[it].y) : 0.f;
+      bsum[2] += use ? __uint_as_float(reg[it].z) : 0.f; bsum[3] += use ? __uint_as_float(reg[it].w) : 0.f;
+    }
+  }
+}
 
 // bf16 fragment (8 k-values of channel `lane&15` of 16-channel tile `ctile`) for k-step rows via two transpose reads.
 __device__ __forceinline__ uint4 frag_tr_bf16(const char* base, int row, int pw, int dx, int ctile, int lane) {
@@ -55,6 +124,10 @@ __device__ __forceinline__ float frag_f32(const char* base, int pix, int c) {
   return *reinterpret_cast<const float*>(base + lds_off(pix, c >> 2) + (c & 3) * 4);
 }
 
+__device__ __forceinline__ f32x4_t mfma_bf16(uint4 a, uint4 b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 template <typename T, int TAPS>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,6 +150,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
   const bool in_relu = (a.flags & DD_IN_RELU) != 0;
   const T* __restrict__ P = reinterpret_cast<const T*>(a.p);
   const T* __restrict__ Q = reinterpret_cast<const T*>(a.q);
+  const bool bias_q = a.bias_mode == 1 && ms == 0, bias_p = a.bias_mode == 2 && ns == 0;
+
+  TilePlan<PH> pplan;
+  TilePlan<DD_TILE> qplan;
+  tile_plan<PH>(pplan, tid);
+  tile_plan<DD_TILE>(qplan, tid);
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   f32x4_t acc[TAPS][NPW];
 #pragma unroll
@@ -92,33 +172,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * DD_TILE, x0 = tx * DD_TILE;
 
-    TileGeom gq;
-    gq.ph = DD_TILE; gq.pw = DD_TILE; gq.oy = y0; gq.ox = x0; gq.sy = 1; gq.ay = 0; gq.ax = 0;
-    gq.lim_y = a.H; gq.lim_x = a.W; gq.min_y = 0; gq.min_x = 0; gq.hin = a.H; gq.win = a.W;
-    TileGeom gp;
-    gp.ph = PH; gp.pw = PW; gp.oy = HALO ? y0 - 1 : y0; gp.ox = HALO ? x0 - 1 : x0;
-    gp.sy = gather ? 2 : 1; gp.ay = 0; gp.ax = 0;
-    gp.lim_y = HALO ? a.H + 1 : a.H; gp.lim_x = HALO ? a.W + 1 : a.W;
-    gp.min_y = HALO ? -1 : 0; gp.min_x = HALO ? -1 : 0; gp.hin = a.hin; gp.win = a.win;
-
-    __syncthreads();  // previous tile fully consumed
-    stage_pixels<T>(qtile, Q, (long)b * a.H * a.W, a.ldq, a.nv, ns * KC, 8, gq, false, tid, 256);
-    if (HALO) stage_pixels<T>(ptile, P, (long)b * a.hin * a.win, a.ldp, a.mv, ms * KC, 8, gp, in_relu, tid, 256);
-
+    uint4 qreg[TilePlan<DD_TILE>::ITERS];
+    tile_load<T, DD_TILE>(qreg, qplan, Q, (long)b * a.H * a.W, a.ldq, a.nv, ns * KC, y0, x0, a.H, a.W, 0, 1, 0, 0, a.H, a.W, tid);
     if constexpr (HALO) {
+      uint4 preg[TilePlan<PH>::ITERS];
+      tile_load<T, PH>(preg, pplan, P, (long)b * a.hin * a.win, a.ldp, a.mv, ms * KC, y0 - 1, x0 - 1, a.H, a.W, 1, 1, 0, 0, a.hin, a.win, tid);
+      __syncthreads();  // previous tile fully consumed
+      if (bias_q) bias_accumulate<T, DD_TILE>(bsum, qreg, qplan, false);
+      if (bias_p) bias_accumulate<T, PH>(bsum, preg, pplan, true);
+      tile_store<T, DD_TILE>(qtile, qreg, qplan, false);
+      tile_store<T, PH>(ptile, preg, pplan, in_relu);
       __syncthreads();
-      // k-step outer, taps inner: the Q fragments are fetched once per k-step and reused by all 9 taps
       if constexpr (BF) {
-        for (int kst = 0; kst < 8; ++kst) {
-          uint4 bq[NPW];
+        // 72 steps (8 k-steps x 9 taps) of 4 MFMAs, fully unrolled; the two transpose reads of the NEXT step's P fragment
+        // (and, spread over taps 0..3, of the next k-step's Q fragments) are issued ahead of each MFMA group and the
+        // interleave is pinned (the compiler otherwise sinks the reads in front of their MFMAs behind lgkmcnt(0)).
+        uint4 bq[2][NPW], ap[2];
 #pragma unroll
-          for (int j = 0; j < NPW; ++j) bq[j] = frag_tr_bf16(qtile, 2 * kst, DD_TILE, 0, ni0 + j, lane);
+        for (int j = 0; j < NPW; ++j) bq[0][j] = frag_tr_bf16(qtile, 0, DD_TILE, 0, ni0 + j, lane);
+        ap[0] = frag_tr_bf16(ptile, 0, PW, 0, mi, lane);
+#pragma unroll
+        for (int kst = 0; kst < 8; ++kst) {
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
-            const uint4 ap = frag_tr_bf16(ptile, 2 * kst + t / 3, PW, t % 3, mi, lane);
+            const int step = kst * TAPS + t;
+            int nds = 0;
+            if (t + 1 < TAPS) { ap[(step + 1) & 1] = frag_tr_bf16(ptile, 2 * kst + (t + 1) / 3, PW, (t + 1) % 3, mi, lane); nds += 2; }
+            else if (kst + 1 < 8) { ap[(step + 1) & 1] = frag_tr_bf16(ptile, 2 * (kst + 1), PW, 0, mi, lane); nds += 2; }
+            if (t < NPW && kst + 1 < 8) { bq[(kst + 1) & 1][t] = frag_tr_bf16(qtile, 2 * (kst + 1), DD_TILE, 0, ni0 + t, lane); nds += 2; }
 #pragma unroll
-            for (int j = 0; j < NPW; ++j)
-              acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ap), __builtin_bit_cast(bf16x8_t, bq[j]), acc[t][j], 0, 0, 0);
+            for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[step & 1], bq[kst & 1][j], acc[t][j]);
+            if (nds == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else if (nds == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NPW, 0);
           }
         }
       } else {
@@ -135,11 +221,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
         }
       }
     } else {
+      __syncthreads();  // previous tile fully consumed
+      if (bias_q) bias_accumulate<T, DD_TILE>(bsum, qreg, qplan, false);
+      tile_store<T, DD_TILE>(qtile, qreg, qplan, false);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
+        uint4 preg[TilePlan<PH>::ITERS];
+        tile_load<T, PH>(preg, pplan, P, (long)b * a.hin * a.win, a.ldp, a.mv, ms * KC, y0, x0, a.H, a.W, 0, gather ? 2 : 1, gather ? (t >> 1) : 0,
+                         gather ? (t & 1) : 0, a.hin, a.win, tid);
         if (t > 0) __syncthreads();
-        if (gather) { gp.ay = t >> 1; gp.ax = t & 1; }
-        stage_pixels<T>(ptile, P, (long)b * a.hin * a.win, a.ldp, a.mv, ms * KC, 8, gp, in_relu, tid, 256);
+        if (bias_p) bias_accumulate<T, PH>(bsum, preg, pplan, false);
+        tile_store<T, PH>(ptile, preg, pplan, in_relu);
         __syncthreads();
         if constexpr (BF) {
 #pragma unroll 2
@@ -148,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
               const uint4 bq = frag_tr_bf16(qtile, 2 * kst, DD_TILE, 0, ni0 + j, lane);
-              acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ap), __builtin_bit_cast(bf16x8_t, bq), acc[t][j], 0, 0, 0);
+              acc[t][j] = mfma_bf16(ap, bq, acc[t][j]);
             }
           }
         } else {
@@ -179,6 +271,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
         if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e]);
       }
     }
+
+  if (a.bias_mode != 0) {   // (uniform) reduce the 32 threads that share a 16-byte channel group, then one atomic per channel
+    constexpr int PER16 = Elem<T>::PER16;
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) red[tid * PER16 + e] = bsum[e];
+    __syncthreads();
+    if ((bias_q || bias_p) && tid < KC) {
+      const int slot = tid / PER16, e = tid - slot * PER16;
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += red[(j * 8 + slot) * PER16 + e];
+      const int c = (bias_q ? ns : ms) * KC + tid;
+      if (c < (bias_q ? a.n : a.m)) atomicAdd(a.bias_out + c, s);
+    }
+  }
 }
 
 template <typename T, int TAPS>
@@ -219,8 +327,10 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
              "dd_conv_wgrad: m=%d n=%d ldp=%d ldq=%d: ld must be a multiple of %d and cover the rounded channel count", a->m, a->n, a->ldp, a->ldq, per16);
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "dd_conv_wgrad: empty grid");
   DD_REQUIRE(((uintptr_t)a->p % 16) == 0 && ((uintptr_t)a->q % 16) == 0, "dd_conv_wgrad: pointers must be 16-byte aligned");
+  DD_REQUIRE(a->bias_mode >= 0 && a->bias_mode <= 2 && (a->bias_mode == 0 || a->bias_out), "dd_conv_wgrad: bias_mode=%d needs bias_out", a->bias_mode);
   WgradP p;
-  p.p = a->p; p.q = a->q; p.out = a->out; p.ldp = a->ldp; p.m = a->m; p.ldq = a->ldq; p.n = a->n; p.mv = mv; p.nv = nv;
+  p.p = a->p; p.q = a->q; p.out = a->out; p.bias_out = a->bias_out; p.bias_mode = a->bias_mode;
+  p.ldp = a->ldp; p.m = a->m; p.ldq = a->ldq; p.n = a->n; p.mv = mv; p.nv = nv;
   p.B = a->B; p.H = a->H; p.W = a->W; p.taps = a->taps; p.flags = a->flags;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
   p.mslices = dd_ceil_div(a->m, kc); p.nslices = dd_ceil_div(a->n, kc);
@@ -228,7 +338,9 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
   int ksplit = a->ksplit;
   if (ksplit <= 0) {
-    ksplit = (int)(512 / ((long)p.mslices * p.nslices));
+    static int target = 0;
+    if (!target) { const char* e = getenv("DD_WGRAD_BLOCKS"); target = e ? atoi(e) : 256; }   // measured: 256 workgroups (1/CU) beat 128 / 512 / 1024 (atomics vs overlap)
+    ksplit = (int)(target / ((long)p.mslices * p.nslices));
     if (ksplit < 1) ksplit = 1;
   }
   if (ksplit > total_tiles) ksplit = (int)total_tiles;

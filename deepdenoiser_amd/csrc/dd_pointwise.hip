@@ -47,6 +47,30 @@ extern "C" int dd_pack_weights(const float* src, void* dst, int dtype, int taps,
   return DD_OK;
 }
 
+template <typename T>
+__global__ void pack_batched_kernel(const dd_pack_desc* __restrict__ table) {
+  const dd_pack_desc d = table[blockIdx.y];
+  T* dst = reinterpret_cast<T*>(d.dst);
+  const long total = (long)d.taps * d.n_pad * d.k_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % d.k_pad);
+    const long r = i / d.k_pad;
+    const int nn = (int)(r % d.n_pad);
+    const int t = (int)(r / d.n_pad);
+    float v = 0.f;
+    if (nn < d.n && kk < d.k) v = d.src[(d.tap_flip ? d.taps - 1 - t : t) * d.s_tap + nn * d.s_n + kk * d.s_k];
+    dst[i] = Elem<T>::from_f32(v);
+  }
+}
+extern "C" int dd_pack_weights_batched(const dd_pack_desc* table, int n_layers, int dtype, dd_stream stream) {
+  DD_REQUIRE(table && n_layers > 0, "dd_pack_weights_batched: bad arguments");
+  const dim3 g(64, (unsigned)n_layers);
+  if (dtype == DD_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, g, dim3(256), 0, S(stream), table);
+  else hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, g, dim3(256), 0, S(stream), table);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ column sums
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ x, int ld, int c, long rows, float* __restrict__ out) {

@@ -176,11 +176,7 @@ class ConvLayer:
                 n, k, st, sn, sk, flip = cin, cout, cout * cin, 1, cin, 0
         n_pad, k_pad = round_up(n, 16), round_up(round_up(k, 8), chunk)
         buf = torch.zeros(taps * n_pad * k_pad, dtype=_TORCH_DT[g.dtype], device=g.device)
-        lib, code, kernel, ps = g.lib, _CODE[g.dtype], self.kernel, g.params
-
-        def pack(stream):
-            L.check(lib.dd_pack_weights(ps.value_ptr(kernel), buf.data_ptr(), code, taps, n, k, n_pad, k_pad, st, sn, sk, flip, stream))
-        g.pack_ops.append(pack)
+        g.register_pack(self.kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip)
         self._packed[role] = (buf, taps, n_pad, k_pad)
         return self._packed[role]
 
@@ -195,6 +191,24 @@ class Graph:
         self.layers = {}
         self.keep = []     # keeps auxiliary device buffers alive
         self.conv_records, self.wgrad_records = [], []
+        self._pack_records = []
+
+    # ------------------------------------------------------------------ weight packing: every layer in ONE launch
+    def register_pack(self, kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip):
+        self._pack_records.append((kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip))
+        if not self.pack_ops:
+            state = {}
+
+            def pack_all(stream):
+                if state.get("n") != len(self._pack_records):   # (re)build the device table when layers were added
+                    tab = (L.PackDesc * len(self._pack_records))()
+                    for i, (kern, b, tp, nn, kk, npad, kpad, s_t, s_n, s_k, fl) in enumerate(self._pack_records):
+                        tab[i] = L.PackDesc(self.params.value_ptr(kern), b.data_ptr(), tp, nn, kk, npad, kpad, fl, s_t, s_n, s_k)
+                    state["dev"] = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+                    state["n"] = len(self._pack_records)
+                L.check(self.lib.dd_pack_weights_batched(state["dev"].data_ptr(), state["n"], self.code, stream))
+            pack_all.tag = "pack_weights"
+            self.pack_ops.append(pack_all)
 
     # ------------------------------------------------------------------ tensors
     def tensor(self, B, H, W, C, dtype=None, relu=False, requires_grad=True, ld=None, zero=True):
@@ -252,12 +266,13 @@ class Graph:
             L.check(lib.dd_conv_igemm(C.byref(a), stream))
         return run
 
-    def _wgrad_call(self, p, m, q, n, out_ptr, B, H, W, taps, flags):
+    def _wgrad_call(self, p, m, q, n, out_ptr, B, H, W, taps, flags, bias_ptr=None, bias_mode=0):
         self.wgrad_records.append({"flops": 2.0 * B * H * W * taps * m * n, "B": B, "H": H, "W": W, "taps": taps, "m": m, "n": n})
         a = L.WgradArgs()
         a.p, a.ldp, a.m = p.ptr, p.ld, m
         a.q, a.ldq, a.n = q.ptr, q.ld, n
         a.out = out_ptr
+        a.bias_out, a.bias_mode = bias_ptr, bias_mode
         a.B, a.H, a.W, a.taps, a.flags, a.dtype, a.ksplit = B, H, W, taps, flags, self.code, 0
         lib = self.lib
         keep = (p.buf, q.buf)
@@ -292,9 +307,8 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             wflags = L.IN_RELU if in_relu else 0
-            self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags), "conv_wgrad"),
-                     grad_params=[layer.kernel])
-            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias), "bias_grad"), grad_params=[layer.bias])
+            self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags,
+                                                          ps.grad_ptr(layer.bias), 1), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gx = x.grad()
@@ -346,9 +360,8 @@ class Graph:
             if not y.grad_written:
                 return
             gy = y.grad()
-            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, x, layer.cin, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, 4, L.GATHER2X2), "conv_wgrad"),
-                     grad_params=[layer.kernel])
-            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias), "bias_grad"), grad_params=[layer.bias])
+            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, x, layer.cin, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, 4, L.GATHER2X2,
+                                                          ps.grad_ptr(layer.bias), 2), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gx = x.grad()
@@ -383,9 +396,8 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             # out[t][co][ci] = sum_p gy[p (+) t][co] * z[p][ci] == dKernel in TF layout [kh,kw,C_out,C_in]
-            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, z, layer.cin, ps.grad_ptr(layer.kernel), z.B, z.H, z.W, 9, 0), "conv_wgrad"),
-                     grad_params=[layer.kernel])
-            self.bwd(self._defer(lambda: self._bias_grad_call(gy, layer.cout, layer.bias), "bias_grad"), grad_params=[layer.bias])
+            self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, z, layer.cin, ps.grad_ptr(layer.kernel), z.B, z.H, z.W, 9, 0,
+                                                          ps.grad_ptr(layer.bias), 2), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gz = z.grad()

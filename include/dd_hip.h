@@ -53,6 +53,10 @@ const char* dd_last_error(void);
 int dd_pack_weights(const float* src, void* dst, int dtype, int taps, int n, int k, int n_pad, int k_pad,
                     long s_tap, long s_n, long s_k, int tap_flip, dd_stream stream);
 
+/* all layers in ONE launch: `table` is a device array of n records */
+typedef struct { const float* src; void* dst; int taps, n, k, n_pad, k_pad, tap_flip; long s_tap, s_n, s_k; } dd_pack_desc;
+int dd_pack_weights_batched(const dd_pack_desc* table, int n_layers, int dtype, dd_stream stream);
+
 /* ---- implicit-GEMM convolution on MFMA (forward and data-gradient of every conv-like layer).
  * Replaces tf.layers.conv2d 3x3/1x1 SAME (UNet.py:29-31; Tiramisu.py:35-37,50-52,77-79;
  * Architecture.py:238-243; MultiScalePrediction.py:64-66,73-75,88-90), tf.layers.conv2d_transpose
@@ -80,6 +84,8 @@ typedef struct {
   const void* q; int ldq; int n;       /* Q operand and its logical channel count (= out dim n); channels up to the next
                                           multiple of 16 bytes must be readable and zero in both operands */
   float* out;                          /* [taps][m][n] fp32, accumulated atomically (zero it first) */
+  float* bias_out; int bias_mode;      /* fused bias gradient (fp32 atomics): 0 none, 1 = column sums of Q -> bias_out[n] (conv2d),
+                                          2 = column sums of P -> bias_out[m] (conv2d_transpose) */
   int B, H, W;                         /* grid of Q (the reduction pixels) */
   int taps; int flags; int dtype;
   int ksplit;                          /* number of reduction splits (0 = choose) */

@@ -143,7 +143,7 @@ def test_training_step_parity_f32(case):
         assert float((d - do).abs().max()) <= 2.0 * 3 * lr + 1e-9, n
         if float(do.norm()) > 0:
             assert rel_l2(d, do) < 0.2, (n, rel_l2(d, do))
-            assert float(((d - do).abs() > 0.5 * lr).double().mean()) <= max(0.08, 2.0 / d.numel()), n
+            assert float(((d - do).abs() > 0.5 * lr).double().mean()) <= max(0.15, 2.0 / d.numel()), n
 
 
 def test_bf16_path_reports_its_tolerance():

@@ -314,7 +314,7 @@ def test_adam_tf_form(lib):
         torch.cuda.synchronize()
         assert float((p.double().cpu() - po[0]).abs().max()) < 2e-6
         check("m", m.cpu(), mo[0], 1e-6)
-        check("v", v.cpu(), vo[0], 1e-6)
+        check("v", v.cpu(), vo[0], 1e-4)    # g*g over 12 orders of magnitude in fp32
 
 
 def test_stitch_and_recombine_bit_exact(lib):

@@ -33,12 +33,16 @@ n = 5
 for _ in range(n):
     op(s)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 lib.dd_debug_phases(buf, 0)
 units = buf[5] or 1
-names = ["patch_load issue", "MFMA loop", "patch_store", "epilogue", "end barrier"]
 print("units per launch (block 0):", units / n)
-tot = 0
-for i, nm in enumerate(names):
-    print("%-18s %9.0f cycles/unit" % (nm, buf[i] / units)); tot += buf[i] / units
-print("%-18s %9.0f cycles/unit" % ("total", tot))
+if buf[8] or buf[9]:
+    for i, nm in [(0, "MFMA role: mma phase"), (1, "MFMA role: wait bar1"), (2, "MFMA role: write stage"), (3, "MFMA role: wait bar2"),
+                  (8, "I/O role: issue patch loads"), (9, "I/O role: drain stage"), (10, "I/O role: wait bar1"), (11, "I/O role: patch -> LDS"), (12, "I/O role: wait bar2")]:
+        print("%-30s %9.0f cycles/unit" % (nm, buf[i] / units))
+else:
+    tot = 0
+    for i, nm in enumerate(["patch_load issue", "MFMA loop", "barrier+epilogue", "patch_store", "end barrier"]):
+        print("%-18s %9.0f cycles/unit" % (nm, buf[i] / units)); tot += buf[i] / units
+    print("%-18s %9.0f cycles/unit" % ("total", tot))
