@@ -127,6 +127,10 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = 
 // Slot s of row r is stored at physical slot s ^ (r & 7): MFMA fragment reads (16 rows x one 16-byte k-group per
 // quarter-wave) then hit 16 distinct 16-byte bank groups per ds_read_b128 service group (conflict-free for any base row).
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * DD_LDS_ROW + ((slot ^ (row & 7)) << 4); }
+// Pixel tiles ([py][px] with `pw` pixels per row) key the swizzle on the COLUMN only: a fragment read covers 16 consecutive px of
+// one row, so this is just as conflict-free, and the lane-dependent part of a read address no longer depends on the row / tap dy
+// (9 taps x 4 rows collapse to 3 x 2 address registers + immediate row offsets -- matters under the 256-VGPR cap).
+__device__ __forceinline__ int lds_pix_off(int py, int px, int pw, int slot) { return (py * pw + px) * DD_LDS_ROW + ((slot ^ (px & 7)) << 4); }
 
 // 16 bytes of zeros: invalid vectors (outside the image / channels >= cin) are read from here, so every tile load is
 // unconditional and needs no select afterwards (one copy per translation unit).

@@ -75,7 +75,7 @@ __device__ __forceinline__ void patch_plan(PatchPlan<HALO>& pl, const ConvP& p, 
     const int py = pix / PH, px = pix - py * PH;
     pl.yx[it] = pix < NPIX ? ((py << 8) | px) : -1;
     pl.rel[it] = (py * p.win + px) * p.ldx;
-    pl.lds[it] = lds_off(pix, slot);
+    pl.lds[it] = lds_pix_off(py, px, PH, slot);
   }
 }
 
@@ -169,8 +169,8 @@ __device__ __forceinline__ void slab_store(char* lds, const uint4 (&reg)[(NT + 1
 // step s (double buffering in registers) and the interleave is PINNED with sched_group_barrier -- left alone, hipcc sinks
 // every weight-fragment ds_read right in front of its 4 MFMAs behind an s_waitcnt lgkmcnt(0) (measured: 29 vs 20 cycles/MFMA).
 template <typename T, int NT, int PH, int NTAPS, int NCH>
-__device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* patch, int pix_shift, const char* wslab0, int wslab_stride, int tap_first,
-                                          int wave, int q, int li) {
+__device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* patch, int shift_y, int shift_x, const char* wslab0, int wslab_stride,
+                                          int tap_first, int wave, int q, int li) {
   constexpr int STEPS = NTAPS * NCH;
   uint4 bf[2][4], af[2][NT];
   auto fetch = [&](int s, uint4 (&b)[4], uint4 (&a)[NT]) {
@@ -179,7 +179,7 @@ __device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* pat
     const int dy = NTAPS == 9 ? tap / 3 : 0, dx = NTAPS == 9 ? tap - dy * 3 : 0;
     const int slot = c * 4 + q;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(patch + lds_off((wave * 4 + r + dy) * PH + li + dx + pix_shift, slot));
+    for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(patch + lds_pix_off(wave * 4 + r + dy + shift_y, li + dx + shift_x, PH, slot));
     const char* wb = wslab0 + ti * wslab_stride;
 #pragma unroll
     for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const uint4*>(wb + lds_off(j * 16 + li, slot));
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     if (RESIDENT) {
       const char* w0 = wbase + (slice * p.taps + tap0) * WB;
-      if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, w0, WB, tap0, wave, q, li);
-      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, w0, WB, tap0, wave, q, li);
+      if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, 0, w0, WB, tap0, wave, q, li);
+      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, 0, w0, WB, tap0, wave, q, li);
     } else {
 #pragma unroll 1
       for (int ti = 0; ti < INNER; ++ti) {
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         if (ti + 1 < INNER) slab_load<T, NT>(wreg, Wp, p, n0, tap + 1, slice, nch * 4, tid);
         else if (has_next) slab_load<T, NT>(wreg, Wp, p, n0, ntap0, nslice, nnch * 4, tid);
         const int dy = HALO ? ti / 3 : 0, dx = HALO ? ti - dy * 3 : 0;
-        if (nch == 2) mma_phase<T, NT, PH, 1, 2>(acc, patch, dy * PH + dx, wdst, 0, 0, wave, q, li);
-        else mma_phase<T, NT, PH, 1, 1>(acc, patch, dy * PH + dx, wdst, 0, 0, wave, q, li);
+        if (nch == 2) mma_phase<T, NT, PH, 1, 2>(acc, patch, dy, dx, wdst, 0, 0, wave, q, li);
+        else mma_phase<T, NT, PH, 1, 1>(acc, patch, dy, dx, wdst, 0, 0, wave, q, li);
       }
     }
     PHASE_T(t2);
@@ -458,8 +458,9 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   char* wbase = smem + PATCH_BYTES + STAGE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool io = wave >= 4;
-  const int w4 = wave & 3, t256 = tid & 255;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform => the role split is a scalar branch
+  const bool io = wave_u >= 4;
+  const int w4 = wave_u & 3, t256 = tid & 255;
   const int nb = blockIdx.x % p.nblk, first = blockIdx.x / p.nblk, stride = gridDim.x / p.nblk;
   const int n0 = nb * NT * 16;
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
@@ -477,51 +478,37 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   if (first >= p.total_tiles) return;
   char* stage = stage_all + w4 * (64 * DD_LDS_ROW);   // MFMA wave w4 writes it, I/O wave w4 drains it
 
-  PatchPlan<HALO> plan;
-  uint4 pre[PatchDim<HALO>::ITERS];
-  if (io) {
-    const int nslabs = p.taps * nslices;
-    for (int sidx = 0; sidx < nslabs; ++sidx) {
-      const int tap = sidx % p.taps, slice = sidx / p.taps;
-      const int nch = min(2, p.kchunks - 2 * slice);
-      uint4 wr[(NT + 1) / 2];
-      slab_load<T, NT>(wr, Wp, p, n0, tap, slice, nch * 4, t256);
-      slab_store<NT>(wbase + sidx * WB, wr, t256);
-    }
-    patch_plan<HALO>(plan, p, t256);
-    patch_load<T, HALO>(pre, plan, X, p, first, 0, 0, min(2, p.kchunks) * 4, t256);
-    patch_store<T, HALO>(patch, pre, plan, in_relu);
-  }
-  __syncthreads();
-
+  // Nothing role-specific is computed before the role branch: the two roles then have disjoint live ranges and each fits the
+  // 256-VGPR budget of an 8-wave workgroup on its own.
   int tile = first, o = 0;
   if (!io) {
     // ------------------------------------------------------------------ MFMA role
-    float biasr[NT][4];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + j * 16 + q * 4 + e;
-        const int bi = pixshuf ? n % cout : n;
-        biasr[j][e] = (p.bias && n < p.n && bi < p.nbias) ? p.bias[bi] : 0.f;
-      }
+    __builtin_amdgcn_s_setprio(2);   // the matrix waves win issue arbitration against the I/O wave sharing their SIMD
+    __syncthreads();                 // weights + first patch staged by the I/O waves
     f32x4_t acc[NT][4];
     while (tile < p.total_tiles) {
       const int slice = HALO ? o : o / p.taps, tap0 = HALO ? 0 : o % p.taps;
       const int nch = min(2, p.kchunks - 2 * slice);
       int no = o + 1, ntile = tile;
       if (no == outer) { no = 0; ntile = tile + stride; }
-      if (o == 0) {
+      if (o == 0) {   // the accumulators start from the bias (re-read per tile: 16 live registers less in the hot loop)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+          f32x4_t bv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[j][r] = f32x4_t{biasr[j][0], biasr[j][1], biasr[j][2], biasr[j][3]};
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + j * 16 + q * 4 + e;
+            const int bi = pixshuf ? n % cout : n;
+            bv[e] = (p.bias && n < p.n && bi < p.nbias) ? p.bias[bi] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[j][r] = bv;
+        }
       }
       const char* w0 = wbase + (slice * p.taps + tap0) * WB;
       PHASE_T(m0);
-      if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, w0, WB, tap0, w4, q, li);
-      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, w0, WB, tap0, w4, q, li);
+      if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, 0, w0, WB, tap0, w4, q, li);
+      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, 0, w0, WB, tap0, w4, q, li);
       PHASE_T(m1);
       __syncthreads();   // bar1: patch consumed by every MFMA wave; stage drained by the I/O waves
       PHASE_T(m2);
@@ -547,6 +534,22 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
     }
   } else {
     // ------------------------------------------------------------------ I/O role
+    PatchPlan<HALO> plan;
+    uint4 pre[PatchDim<HALO>::ITERS];
+    {
+      const int nslabs = p.taps * nslices;
+      for (int sidx = 0; sidx < nslabs; ++sidx) {
+        const int tap = sidx % p.taps, slice = sidx / p.taps;
+        const int nch = min(2, p.kchunks - 2 * slice);
+        uint4 wr[(NT + 1) / 2];
+        slab_load<T, NT>(wr, Wp, p, n0, tap, slice, nch * 4, t256);
+        slab_store<NT>(wbase + sidx * WB, wr, t256);
+      }
+      patch_plan<HALO>(plan, p, t256);
+      patch_load<T, HALO>(pre, plan, X, p, first, 0, 0, min(2, p.kchunks) * 4, t256);
+      patch_store<T, HALO>(patch, pre, plan, in_relu);
+    }
+    __syncthreads();
     constexpr int ESLOTS = 8;
     int e_lds[ESLOTS], e_pix[ESLOTS];
     const int e_slot = lane & 7;

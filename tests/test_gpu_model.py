@@ -143,7 +143,8 @@ def test_training_step_parity_f32(case):
         assert float((d - do).abs().max()) <= 2.0 * 3 * lr + 1e-9, n
         if float(do.norm()) > 0:
             assert rel_l2(d, do) < 0.2, (n, rel_l2(d, do))
-            assert float(((d - do).abs() > 0.5 * lr).double().mean()) <= max(0.15, 2.0 / d.numel()), n
+            # small tensors (biases): allow a fixed handful of noise-level entries instead of a fraction
+            assert int(((d - do).abs() > 0.5 * lr).sum()) <= max(0.15 * d.numel(), 4), n
 
 
 def test_bf16_path_reports_its_tolerance():
