@@ -51,31 +51,49 @@ def conv_flops(prog):
     return total
 
 
-def cpu_baseline(aj, tj, H, W, budget_s=25.0):
-    """The oracle timed on the host cores: fwd + loss + bwd + Adam of the same network, bounded sample."""
+def cpu_baseline(aj, tj, H, W, budget_s=20.0):
+    """The oracle timed on the host cores: fwd + loss + bwd + Adam of the same network on a bounded sample.
+    The thread count is chosen by a short sweep (oneDNN with every hardware thread of a 2-socket host on a B=4 batch is far
+    slower than a few dozen threads); `cores` reports the threads actually used."""
     from oracle.model import OracleArchitecture
     from oracle import training as OT
     from deepdenoiser_amd.naming import Naming
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
-    B = 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    B = 4
     o = OracleArchitecture(aj, dtype=torch.float32, seed=2)
     g = torch.Generator().manual_seed(0)
     feats = {Naming.source_feature_name(f.name, index=0): torch.randn(B, H, W, f.channels, generator=g).abs() for f in o.features + o.auxiliary}
     labels = {Naming.target_feature_name(f.name): torch.randn(B, H, W, f.channels, generator=g).abs() for f in o.features}
     state = ([], [])
-    OT.train_step(o, aj, tj, feats, labels, state, 1)       # warm-up (allocations, oneDNN primitive caches)
-    t0 = time.time()
-    n = 0
+    step = [0]
+
+    def one():
+        step[0] += 1
+        t = time.time()
+        OT.train_step(o, aj, tj, feats, labels, state, step[0])
+        return time.time() - t
+
+    best_t, best_n = None, None
+    sweep_start = time.time()
+    for n in sorted({c for c in (8, 16, 32, 64, min(avail, 64)) if c <= avail}):      # all 256 threads of the GPU box: 113 s per step (measured)
+        torch.set_num_threads(n)
+        one()                                   # warm-up (allocations, oneDNN primitive caches)
+        t = one()
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+        if time.time() - sweep_start > budget_s:
+            break
+    torch.set_num_threads(best_n)
+    t0, n = time.time(), 0
     while True:
-        OT.train_step(o, aj, tj, feats, labels, state, n + 2)
+        one()
         n += 1
-        if time.time() - t0 > budget_s or n >= 10:
+        if time.time() - t0 > budget_s / 2 or n >= 20:
             break
     dt = time.time() - t0
-    return {"value": B * n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+    return {"value": B * n / dt, "unit": "tiles/s", "cores": best_n, "host_threads_available": avail, "kind": "port",
             "sample": "%d training steps of %d tile(s) %dx%dx32ch, same network, fp32, PyTorch-CPU restatement of the TF graph "
-                      "(oracle/; TensorFlow itself is not installable)" % (n, B, H, W)}
+                      "(oracle/; TensorFlow itself is not installable); thread count = best of a short sweep" % (n, B, H, W)}
 
 
 def main():
@@ -88,6 +106,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="PCIe-inclusive variant (NOT the headline value): every step first copies its batch from pinned host memory")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,12 +137,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.host_inputs:
+        hf = {k: v.cpu().pin_memory() for k, v in feats.items()}
+        hl = {k: v.cpu().pin_memory() for k, v in labels.items()}
+
+        def one_step():
+            trainer.program.set_inputs(hf, hl, non_blocking=True)
+            trainer.step()
+    else:
+        one_step = trainer.step
+
     for _ in range(args.warmup):
-        trainer.step()
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step()
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     loss = float(trainer.program.loss_buf)
@@ -151,7 +181,7 @@ def main():
             "config": {"workload": "BASELINE config 2: U-Net [64,96,128]x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction, "
                                    "32-channel render-pass stack, %dx%d tiles, full training step (fwd+SMAPE loss+bwd+Adam)" % (H, W),
                        "tiles_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "hipgraph": not args.no_graph, "final_loss": loss},
+                       "hipgraph": not args.no_graph, "final_loss": loss, "inputs": "pinned host, copied every step" if args.host_inputs else "resident in HBM"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -7,22 +7,82 @@ across ranks (per-rank data); gradients live in ONE flat fp32 arena in variable-
 are zero-copy slices of it.  Backward runs in reverse creation order => the arena becomes final from its TAIL; the step
 is cut into hipGraph segments at bucket boundaries and each bucket's RCCL all-reduce is issued on a side stream as soon
 as its segment finishes, overlapping the remaining backward.  The payload is small (~6.8 MB fp32 for the flagship
-config) and latency-bound on xGMI, so the bucket count is kept small (2-4).
+config) and latency-bound on xGMI, so the bucket count is kept small (default 4).
 """
 import torch
 
 from . import _lib as L
 
 
+def plan_buckets(params, last_writer, n_ops, total, n_buckets):
+    """Cut a reverse program of `n_ops` ops into `n_buckets` segments by gradient readiness.  Pure integer logic (CPU-testable).
+
+    params:      [(name, offset, size)] layout of the flat gradient arena (variable-creation order)
+    last_writer: {name: index of the LAST op of the reverse program that writes this parameter's gradient}
+    Returns [(op_begin, op_end, lo, hi)]: after ops [op_begin, op_end) have run, arena slice [lo, hi) is final and may be
+    all-reduced while later segments run.  Segments tile [0, n_ops) in order; slices tile [0, total), taken from the TAIL of
+    the arena first (backward runs in reverse creation order, so the tail is ready first)."""
+    n_buckets = max(1, min(n_buckets, total))
+    edges = [total * k // n_buckets for k in range(n_buckets + 1)]
+    out, begin, done = [], 0, 0
+    for k in reversed(range(n_buckets)):
+        lo, hi = edges[k], edges[k + 1]
+        ready = 0
+        for name, off, size in params:
+            if off < hi and off + size > lo:
+                ready = max(ready, last_writer.get(name, -1) + 1)
+        done = max(done, ready)
+        out.append([begin, done, lo, hi])
+        begin = done
+    out[-1][1] = n_ops                      # trailing ops that write no parameter gradient (input-side glue)
+    return [tuple(x) for x in out]
+
+
+class GradientReducer:
+    """Sum all-reduce of slices of the flat gradient arena, issued asynchronously (side HIP stream on GPU, async work handles on
+    CPU/gloo) so that it overlaps the rest of backward.  `wait()` joins everything before the optimizer reads the arena."""
+
+    def __init__(self, grads, world_size, group=None):
+        self.grads, self.world, self.group = grads, world_size, group
+        self._stream = torch.cuda.Stream(device=grads.device) if (world_size > 1 and grads.is_cuda) else None
+        self._works = []
+
+    def launch(self, lo, hi):
+        if self.world <= 1 or hi <= lo:
+            return
+        import torch.distributed as dist
+        view = self.grads[lo:hi]
+        if self._stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(ev)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    @property
+    def grad_scale(self):
+        """Factor the optimizer applies to the summed gradients (mean over ranks; every rank's loss is a mean over its shard)."""
+        return 1.0 / self.world
+
+
 class Trainer:
-    def __init__(self, arch, training_json, B, H, W, world_size=1, use_graph=True, n_buckets=2):
+    def __init__(self, arch, training_json, B, H, W, world_size=1, use_graph=True, n_buckets=4, force_segments=False):
         self.arch, self.world = arch, world_size
         self.program = arch.program(B, H, W, training_json=training_json)
         self.use_graph = use_graph
-        self.n_buckets = max(1, n_buckets) if world_size > 1 else 1
-        self._segments = None          # list of (ops, bucket slice or None)
+        self.n_buckets = max(1, n_buckets) if (world_size > 1 or force_segments) else 1
+        self._segments = None          # list of (ops, arena slice)
         self._graphs = None
-        self._comm_stream = torch.cuda.Stream(device=arch.device) if world_size > 1 else None
+        self.reducer = GradientReducer(arch.params.grads, world_size)
         self._warm = 0
 
     # ------------------------------------------------------------------ segmentation by gradient readiness
@@ -31,34 +91,12 @@ class Trainer:
         g = prog.g
         head = list(g.pack_ops) + list(g.fwd_ops)
         bwd = list(g.bwd_ops)
-        if self.n_buckets == 1:
-            self._segments = [(head + bwd, (0, ps.values.numel()) if self.world > 1 else None)]
-            return
         last_writer = {}
         for i, op in enumerate(bwd):
             for p in getattr(op, "grad_params", ()):
                 last_writer[p.name] = i
-        # equal-sized contiguous buckets over the arena, ordered from the tail (ready first)
-        total = ps.values.numel()
-        edges = [total * k // self.n_buckets for k in range(self.n_buckets + 1)]
-        buckets = []
-        for k in reversed(range(self.n_buckets)):
-            lo, hi = edges[k], edges[k + 1]
-            ready = -1
-            for p in ps.params:
-                if p.offset < hi and p.offset + p.size > lo:
-                    ready = max(ready, last_writer.get(p.name, -1))
-            buckets.append((lo, hi, ready))
-        segments, start = [], 0
-        done = -1
-        for lo, hi, ready in buckets:
-            ready = max(ready, done)
-            ops = bwd[start:ready + 1]
-            segments.append([ops, (lo, hi)])
-            start, done = ready + 1, ready
-        segments[-1][0] = segments[-1][0] + bwd[start:]
-        segments[0][0] = head + segments[0][0]
-        self._segments = [(ops, sl) for ops, sl in segments]
+        plan = plan_buckets([(p.name, p.offset, p.size) for p in ps.params], last_writer, len(bwd), ps.values.numel(), self.n_buckets)
+        self._segments = [((head if k == 0 else []) + bwd[b:e], (lo, hi)) for k, (b, e, lo, hi) in enumerate(plan)]
 
     def _run_segment_eager(self, idx):
         ops, _ = self._segments[idx]
@@ -76,30 +114,19 @@ class Trainer:
 
     # ------------------------------------------------------------------ one optimisation step
     def step(self):
-        prog, ps = self.program, self.arch.params
+        prog = self.program
         if self._segments is None:
             self._build_segments()
         if self.use_graph and self._graphs is None and self._warm >= 2:
             torch.cuda.synchronize()
             self._capture()
         self._warm += 1
-        grad_scale = 1.0
-        if self.world > 1:
-            import torch.distributed as dist
-            grad_scale = 1.0 / self.world
-        works = []
         for idx, (ops, sl) in enumerate(self._segments):
             if self._graphs is not None:
                 self._graphs[idx].replay()
             else:
                 self._run_segment_eager(idx)
-            if self.world > 1 and sl is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(self._comm_stream):
-                    self._comm_stream.wait_event(ev)
-                    dist.all_reduce(ps.grads[sl[0]:sl[1]], op=dist.ReduceOp.SUM)
-        if self.world > 1:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
-        prog.adam(grad_scale=grad_scale)
+            self.reducer.launch(*sl)          # RCCL all-reduce of the slice that just became final (no-op for world 1)
+        self.reducer.wait()
+        prog.adam(grad_scale=self.reducer.grad_scale)
         return prog.loss_buf

@@ -165,3 +165,33 @@ def test_bf16_path_reports_its_tolerance():
     errs = [rel_l2(arch.params.grad(p).cpu(), go) for p, go in zip(arch.params.params, grads_o) if float(go.norm()) > 0]
     print("bf16 gradient rel-L2: median %.3e max %.3e" % (sorted(errs)[len(errs) // 2], max(errs)))
     assert sorted(errs)[len(errs) // 2] < 0.25
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_segmented_trainer_matches_plain_step(use_graph):
+    """The data-parallel Trainer (reverse program cut into bucket segments, hipGraph per segment) must compute the same step
+    as the unsegmented program; world_size 1 so the all-reduce is a no-op (RCCL path itself: tests/test_distributed.py on gloo)."""
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.training import Trainer
+    aj, tj, B, H, W = configs.cfg2_unet_kpcn(), configs.bench_training(), 2, 32, 32
+    ref = Architecture(aj, device="cuda", dtype="f32", seed=2)
+    prog = ref.program(B, H, W, training_json=tj)
+    seg = Architecture(aj, device="cuda", dtype="f32", seed=2)
+    trainer = Trainer(seg, tj, B, H, W, world_size=1, use_graph=use_graph, n_buckets=3, force_segments=True)
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(oracle, B, H, W)
+    dev = {k: v.cuda() for k, v in feats.items()}
+    devl = {k: v.cuda() for k, v in labels.items()}
+    trainer.program.set_inputs(dev, devl)
+    for step in range(4):                      # graphs are captured after two eager steps
+        loss_ref = float(prog.train_step(dev, devl))
+        loss_seg = float(trainer.step())
+        assert abs(loss_ref - loss_seg) <= 1e-5 * abs(loss_ref), (step, loss_ref, loss_seg)
+    assert len(trainer._segments) == 3 and all(len(ops) > 0 for ops, _ in trainer._segments)
+    assert (trainer._graphs is not None) == use_graph
+    lr = tj["learning_rate"]
+    # fp32 atomics make wgrad sums order-dependent: compare displacements, not bits
+    d = (ref.params.values - seg.params.values).abs()
+    assert float(d.max()) <= 2 * 4 * lr
+    assert float((d > 0.5 * lr).float().mean()) < 0.02
