@@ -161,46 +161,90 @@ __device__ __forceinline__ void slab_store(char* lds, const uint4 (&reg)[(NT + 1
   }
 }
 
+// Every (tap, slice) weight slab of this workgroup's channel block -> LDS, once per launch.  BATCH 16-byte vectors per thread are in
+// flight before the first is stored: staging one slab at a time costs one full memory round trip per slab, and with every
+// workgroup of the launch doing it at once that was 34 us of a 63 us launch (64->64 3x3, 18 slabs; tools/phase_profile.py).
+template <typename T, int NT, int NTHREADS, int BATCH>
+__device__ __forceinline__ void stage_weights(char* wbase, const T* __restrict__ Wp, const ConvP& p, int n0, int nslices, int tid) {
+  constexpr int KC = DD_LDS_ROW / (int)sizeof(T), ROWS = NT * 16, WB = ROWS * DD_LDS_ROW;
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
+  const int total = p.taps * nslices * ROWS * 8;
+  for (int base = 0; base < total; base += NTHREADS * BATCH) {
+    uint4 reg[BATCH];
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int v = base + b * NTHREADS + tid;
+      const int slot = v & 7, r = v >> 3;
+      const int row = r % ROWS, sidx = r / ROWS;
+      const int slice = sidx / p.taps, tap = sidx - slice * p.taps;
+      const int nslots = min(2, p.kchunks - 2 * slice) * 4;
+      const int ng = n0 + row;
+      const bool ok = v < total && slot < nslots && ng < p.n_pad;
+      reg[b] = *reinterpret_cast<const uint4*>(ok ? Wp + ((long)tap * p.n_pad + ng) * p.k_pad + slice * KC + slot * Elem<T>::PER16 : zero);
+    }
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int v = base + b * NTHREADS + tid;
+      const int slot = v & 7, r = v >> 3;
+      const int row = r % ROWS, sidx = r / ROWS;
+      if (v < total) *reinterpret_cast<uint4*>(wbase + sidx * WB + lds_off(row, slot)) = reg[b];
+    }
+  }
+}
+
 #ifndef DD_SCHED
 #define DD_SCHED 2
 #endif
 
-// MFMA work of `NTAPS` consecutive taps on one staged patch: all fragment reads of step s+1 are issued before the MFMAs of
-// step s (double buffering in registers) and the interleave is PINNED with sched_group_barrier -- left alone, hipcc sinks
-// every weight-fragment ds_read right in front of its 4 MFMAs behind an s_waitcnt lgkmcnt(0) (measured: 29 vs 20 cycles/MFMA).
+// MFMA work of `NTAPS` consecutive taps on one staged patch.  Fragments are double-buffered in registers: the 4+NT fragment reads
+// of step s+1 are spread between the 4*NT MFMAs of step s, each read >= 11 MFMAs (~180 cycles) ahead of its first use, in the
+// order the MFMAs need them (w0, p0..p3, w1..).  The interleave is pinned with sched_barrier(0): left alone -- and also with
+// sched_group_barrier, which fixes only HOW MANY reads go between MFMAs, not WHICH -- hipcc issues each weight fragment 2 MFMAs
+// before its use, and with one MFMA wave per SIMD every such read stalls the matrix pipe (measured 45 vs 16 cycles per MFMA).
 template <typename T, int NT, int PH, int NTAPS, int NCH>
 __device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* patch, int shift_y, int shift_x, const char* wslab0, int wslab_stride,
                                           int tap_first, int wave, int q, int li) {
-  constexpr int STEPS = NTAPS * NCH;
+  constexpr int STEPS = NTAPS * NCH, NLOAD = 4 + NT, NMMA = 4 * NT;
   uint4 bf[2][4], af[2][NT];
-  auto fetch = [&](int s, uint4 (&b)[4], uint4 (&a)[NT]) {
+  // load item i of step s: i = 0 -> weight fragment 0, 1..4 -> pixel fragments 0..3, 5.. -> weight fragments 1..
+  auto load_item = [&](int s, int i) {
     const int ti = s / NCH, c = s - ti * NCH;
     const int tap = tap_first + ti;
     const int dy = NTAPS == 9 ? tap / 3 : 0, dx = NTAPS == 9 ? tap - dy * 3 : 0;
     const int slot = c * 4 + q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const uint4*>(patch + lds_pix_off(wave * 4 + r + dy + shift_y, li + dx + shift_x, PH, slot));
-    const char* wb = wslab0 + ti * wslab_stride;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const uint4*>(wb + lds_off(j * 16 + li, slot));
+    if (i >= 1 && i <= 4) {
+      const int r = i - 1;
+      bf[s & 1][r] = *reinterpret_cast<const uint4*>(patch + lds_pix_off(wave * 4 + r + dy + shift_y, li + dx + shift_x, PH, slot));
+    } else {
+      const int j = i == 0 ? 0 : i - 4;
+      af[s & 1][j] = *reinterpret_cast<const uint4*>(wslab0 + ti * wslab_stride + lds_off(j * 16 + li, slot));
+    }
   };
-  fetch(0, bf[0], af[0]);
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) load_item(0, i);
+#ifdef DD_EXP_NO_DSREAD   // experiment: MFMA loop without fragment reads (results are garbage)
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) load_item(1, i);
+#endif
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    if (s + 1 < STEPS) fetch(s + 1, bf[(s + 1) & 1], af[(s + 1) & 1]);
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[j][r] = mma16<T>(af[s & 1][j], bf[s & 1][r], acc[j][r]);
-#if DD_SCHED == 2
-    if (sizeof(T) == 2) {
-#pragma unroll
-      for (int i = 0; i < 4 + NT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // 1 DS read of the next step
-        __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (4 + NT), 0);     // MFMAs of this step
-      }
-    }
+    for (int i = 0; i < NLOAD; ++i) {
+#ifndef DD_EXP_NO_DSREAD
+      if (s + 1 < STEPS) load_item(s + 1, i);
 #endif
+#if DD_SCHED == 2
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int m = (i * NMMA) / NLOAD; m < ((i + 1) * NMMA) / NLOAD; ++m) {
+        const int j = m >> 2, r = m & 3;
+        acc[j][r] = mma16<T>(af[s & 1][j], bf[s & 1][r], acc[j][r]);
+      }
+#if DD_SCHED == 2
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
   }
 }
 
@@ -225,16 +269,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   const bool in_relu = (p.flags & DD_IN_RELU) != 0;
   if (first >= p.total_tiles) return;
 
-  if (RESIDENT) {   // every (tap, slice) slab of this channel block, once per workgroup
-    const int nslabs = p.taps * nslices;
-    for (int sidx = 0; sidx < nslabs; ++sidx) {
-      const int tap = sidx % p.taps, slice = sidx / p.taps;
-      const int nch = min(2, p.kchunks - 2 * slice);
-      uint4 wr[(NT + 1) / 2];
-      slab_load<T, NT>(wr, Wp, p, n0, tap, slice, nch * 4, tid);
-      slab_store<NT>(wbase + sidx * WB, wr, tid);
-    }
-  }
+  if (RESIDENT) stage_weights<T, NT, 256, 8>(wbase, Wp, p, n0, nslices, tid);
 
   const bool pixshuf = (p.flags & DD_PIXSHUF) != 0;
   const int cout = pixshuf ? p.n / 4 : p.n;
@@ -477,6 +512,19 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   const bool out_relu = (p.flags & DD_OUT_RELU) != 0, accum = (p.flags & DD_ACCUM) != 0;
   if (first >= p.total_tiles) return;
   char* stage = stage_all + w4 * (64 * DD_LDS_ROW);   // MFMA wave w4 writes it, I/O wave w4 drains it
+#ifdef DD_PROFILE_PHASES
+  const unsigned long long k_t0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
+#endif
+
+  stage_weights<T, NT, 512, 9>(wbase, Wp, p, n0, nslices, tid);   // all 8 waves; made visible by the roles' first barrier
+  // The bias lives in LDS too: re-reading it from global memory at every tile start put a full (loaded-machine) memory latency
+  // in front of each tile's first MFMA -- half of the launch time.
+  float* bias_lds = reinterpret_cast<float*>(wbase + p.taps * nslices * WB);
+  if (tid < NT * 16) {
+    const int n = n0 + tid;
+    const int bi = pixshuf ? n % cout : n;
+    bias_lds[tid] = (p.bias && n < p.n && bi < p.nbias) ? p.bias[bi] : 0.f;
+  }
 
   // Nothing role-specific is computed before the role branch: the two roles then have disjoint live ranges and each fits the
   // 256-VGPR budget of an 8-wave workgroup on its own.
@@ -491,16 +539,10 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       const int nch = min(2, p.kchunks - 2 * slice);
       int no = o + 1, ntile = tile;
       if (no == outer) { no = 0; ntile = tile + stride; }
-      if (o == 0) {   // the accumulators start from the bias (re-read per tile: 16 live registers less in the hot loop)
+      if (o == 0) {   // the accumulators start from the bias
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          f32x4_t bv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = n0 + j * 16 + q * 4 + e;
-            const int bi = pixshuf ? n % cout : n;
-            bv[e] = (p.bias && n < p.n && bi < p.nbias) ? p.bias[bi] : 0.f;
-          }
+          const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + j * 16 + q * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[j][r] = bv;
         }
@@ -532,19 +574,14 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       tile = ntile;
       o = no;
     }
+#ifdef DD_PROFILE_PHASES
+    if (blockIdx.x == 0 && tid == 0) { dd_phase_cycles[14] += __builtin_readcyclecounter() - k_t0; dd_phase_cycles[15] += wall_clock64() - k_w0; }
+#endif
   } else {
     // ------------------------------------------------------------------ I/O role
     PatchPlan<HALO> plan;
     uint4 pre[PatchDim<HALO>::ITERS];
     {
-      const int nslabs = p.taps * nslices;
-      for (int sidx = 0; sidx < nslabs; ++sidx) {
-        const int tap = sidx % p.taps, slice = sidx / p.taps;
-        const int nch = min(2, p.kchunks - 2 * slice);
-        uint4 wr[(NT + 1) / 2];
-        slab_load<T, NT>(wr, Wp, p, n0, tap, slice, nch * 4, t256);
-        slab_store<NT>(wbase + sidx * WB, wr, t256);
-      }
       patch_plan<HALO>(plan, p, t256);
       patch_load<T, HALO>(pre, plan, X, p, first, 0, 0, min(2, p.kchunks) * 4, t256);
       patch_store<T, HALO>(patch, pre, plan, in_relu);
@@ -616,13 +653,19 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       const int nslice = HALO ? no : no / p.taps, ntap0 = HALO ? 0 : no % p.taps;
       const int nnch = min(2, p.kchunks - 2 * nslice);
       PHASE_T(i0);
+#ifndef DD_EXP_NO_IO
       if (has_next) patch_load<T, HALO>(pre, plan, X, p, ntile, nslice, ntap0, nnch * 4, t256);
+#endif
       PHASE_T(i1);
+#ifndef DD_EXP_NO_IO
       if (pending >= 0) { drain(pending); pending = -1; }
+#endif
       PHASE_T(i2);
       __syncthreads();   // bar1
       PHASE_T(i3);
+#ifndef DD_EXP_NO_IO
       if (has_next) patch_store<T, HALO>(patch, pre, plan, in_relu);
+#endif
       PHASE_T(i4);
       __syncthreads();   // bar2
       PHASE_T(i5);
@@ -665,7 +708,7 @@ int launch(const ConvP& p, int nslabs, hipStream_t stream) {
 
 template <int NT, bool HALO>
 int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
-  const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + (size_t)nslabs * NT * 16 * DD_LDS_ROW;
+  const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + (size_t)nslabs * NT * 16 * DD_LDS_ROW + NT * 16 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<NT, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

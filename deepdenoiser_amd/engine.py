@@ -264,6 +264,7 @@ class Graph:
 
         def run(stream, a=a, keep=keep):
             L.check(lib.dd_conv_igemm(C.byref(a), stream))
+        run.info = dict(self.conv_records[-1], flags=flags) if nk is not None else None
         return run
 
     def _wgrad_call(self, p, m, q, n, out_ptr, B, H, W, taps, flags, bias_ptr=None, bias_mode=0):
@@ -279,6 +280,7 @@ class Graph:
 
         def run(stream, a=a, keep=keep):
             L.check(lib.dd_conv_wgrad(C.byref(a), stream))
+        run.info = self.wgrad_records[-1]
         return run
 
     def _bias_grad_call(self, gy, cout, bias_param):
@@ -451,8 +453,10 @@ class Graph:
         def run(stream):
             if not cell:
                 cell.append(make())
+                run.info = getattr(cell[0], "info", None)
             cell[0](stream)
         run.tag = tag
+        run.info = None
         return run
 
     def finalize(self, seed=2):

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "deepdenoiser_amd", "csrc")
-so = os.path.join(ROOT, "build", "libdd_prof.so")
+so = os.environ.get("DD_PROF_SO", os.path.join(ROOT, "build", "libdd_prof.so"))
 os.makedirs(os.path.dirname(so), exist_ok=True)
 extra = [a for a in sys.argv if a.startswith("-D")]
 sys.argv = [a for a in sys.argv if not a.startswith("-D")]
@@ -37,6 +37,8 @@ buf = (C.c_ulonglong * 16)()
 lib.dd_debug_phases(buf, 0)
 units = buf[5] or 1
 print("units per launch (block 0):", units / n)
+if buf[15]:
+    print("block 0, whole kernel: %.0f ticks, %.2f us by the 100 MHz wall clock => counter runs at %.0f MHz" % (buf[14] / n, buf[15] / n / 100.0, buf[14] / (buf[15] / 100.0)))
 if buf[8] or buf[9]:
     for i, nm in [(0, "MFMA role: mma phase"), (1, "MFMA role: wait bar1"), (2, "MFMA role: write stage"), (3, "MFMA role: wait bar2"),
                   (8, "I/O role: issue patch loads"), (9, "I/O role: drain stage"), (10, "I/O role: wait bar1"), (11, "I/O role: patch -> LDS"), (12, "I/O role: wait bar2")]:
