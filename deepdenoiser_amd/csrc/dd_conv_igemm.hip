@@ -192,6 +192,26 @@ __device__ __forceinline__ void stage_weights(char* wbase, const T* __restrict__
   }
 }
 
+// XCD-aware work assignment.  Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8) and every XCD
+// has its own 4 MiB L2.  XCD x therefore owns a CONTIGUOUS range of tiles (whole images when B % 8 == 0) and all channel blocks
+// of a tile run on the same XCD: halo rows shared by neighbouring tiles and the patch re-read by the other channel blocks hit
+// in that XCD's L2 instead of going to the memory side.  (Fallback when the grid is not a multiple of 8 * nblk: plain striding.)
+struct TileWalk { int nb, first, end, step; };
+__device__ __forceinline__ TileWalk tile_walk(const ConvP& p) {
+  const int b = blockIdx.x, G = gridDim.x;
+  TileWalk w;
+  if (G % (8 * p.nblk) == 0) {
+    const int xcd = b & 7, i = b >> 3;
+    w.nb = i % p.nblk;
+    w.step = G / (8 * p.nblk);
+    w.first = (int)((long)p.total_tiles * xcd / 8) + i / p.nblk;
+    w.end = (int)((long)p.total_tiles * (xcd + 1) / 8);
+  } else {
+    w.nb = b % p.nblk; w.first = b / p.nblk; w.step = G / p.nblk; w.end = p.total_tiles;
+  }
+  return w;
+}
+
 #ifndef DD_SCHED
 #define DD_SCHED 2
 #endif
@@ -259,7 +279,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   char* wbase = smem + PATCH_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = blockIdx.x % p.nblk, first = blockIdx.x / p.nblk, stride = gridDim.x / p.nblk;
+  const TileWalk walk = tile_walk(p);
+  const int nb = walk.nb, first = walk.first, stride = walk.step, tiles_end = walk.end;
   const int n0 = nb * NT * 16;
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(p.wp);
@@ -267,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   const int outer = HALO ? nslices : nslices * p.taps;   // units per tile
   const int q = lane >> 4, li = lane & 15;
   const bool in_relu = (p.flags & DD_IN_RELU) != 0;
-  if (first >= p.total_tiles) return;
+  if (first >= tiles_end) return;
 
   if (RESIDENT) stage_weights<T, NT, 256, 8>(wbase, Wp, p, n0, nslices, tid);
 
@@ -314,13 +335,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   }
   __syncthreads();
 
-  while (tile < p.total_tiles) {
+  while (tile < tiles_end) {
     // this unit: outer step o of `tile`
     const int slice = HALO ? o : o / p.taps, tap0 = HALO ? 0 : o % p.taps;
     const int nch = min(2, p.kchunks - 2 * slice);
     int no = o + 1, ntile = tile;
     if (no == outer) { no = 0; ntile = tile + stride; }
-    const bool has_next = ntile < p.total_tiles;
+    const bool has_next = ntile < tiles_end;
     const int nslice = HALO ? no : no / p.taps, ntap0 = HALO ? 0 : no % p.taps;
     const int nnch = min(2, p.kchunks - 2 * nslice);
     PHASE_T(t0);
@@ -496,7 +517,8 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform => the role split is a scalar branch
   const bool io = wave_u >= 4;
   const int w4 = wave_u & 3, t256 = tid & 255;
-  const int nb = blockIdx.x % p.nblk, first = blockIdx.x / p.nblk, stride = gridDim.x / p.nblk;
+  const TileWalk walk = tile_walk(p);
+  const int nb = walk.nb, first = walk.first, stride = walk.step, tiles_end = walk.end;
   const int n0 = nb * NT * 16;
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(p.wp);
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   const T* __restrict__ M = reinterpret_cast<const T*>(p.mask);
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
   const bool out_relu = (p.flags & DD_OUT_RELU) != 0, accum = (p.flags & DD_ACCUM) != 0;
-  if (first >= p.total_tiles) return;
+  if (first >= tiles_end) return;
   char* stage = stage_all + w4 * (64 * DD_LDS_ROW);   // MFMA wave w4 writes it, I/O wave w4 drains it
 #ifdef DD_PROFILE_PHASES
   const unsigned long long k_t0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
@@ -534,7 +556,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
     __builtin_amdgcn_s_setprio(2);   // the matrix waves win issue arbitration against the I/O wave sharing their SIMD
     __syncthreads();                 // weights + first patch staged by the I/O waves
     f32x4_t acc[NT][4];
-    while (tile < p.total_tiles) {
+    while (tile < tiles_end) {
       const int slice = HALO ? o : o / p.taps, tap0 = HALO ? 0 : o % p.taps;
       const int nch = min(2, p.kchunks - 2 * slice);
       int no = o + 1, ntile = tile;
@@ -646,10 +668,10 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
     };
 
     int pending = -1;
-    while (tile < p.total_tiles) {
+    while (tile < tiles_end) {
       int no = o + 1, ntile = tile;
       if (no == outer) { no = 0; ntile = tile + stride; }
-      const bool has_next = ntile < p.total_tiles;
+      const bool has_next = ntile < tiles_end;
       const int nslice = HALO ? no : no / p.taps, ntap0 = HALO ? 0 : no % p.taps;
       const int nnch = min(2, p.kchunks - 2 * nslice);
       PHASE_T(i0);
@@ -680,6 +702,22 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
 
 int g_num_cus = 0;
 
+// Persistent grid: at most `slots` workgroups, a multiple of the channel-block count and -- when that idles under 7 % of the slots and
+// every XCD still gets work -- of 8 * nblk, which turns on the XCD-aware tile assignment (tile_walk).
+static long grid_size(long slots, const ConvP& p) {
+  static int xcd_mode = -1;
+  if (xcd_mode < 0) { const char* e = getenv("DD_CONV_XCD"); xcd_mode = e ? atoi(e) : 1; }
+  const long need = (long)p.total_tiles * p.nblk;
+  long wgs = slots / p.nblk * p.nblk;
+  if (wgs < p.nblk) wgs = p.nblk;
+  if (wgs > need) wgs = need;
+  const long unit = 8L * p.nblk;
+  const long xw = wgs / unit * unit;
+  if (xcd_mode && xw > 0 && xw * 100 >= wgs * 93 && p.total_tiles >= 8 * (xw / unit)) return xw;
+  if (!xcd_mode && wgs % unit == 0 && wgs > p.nblk) wgs -= p.nblk;     // DD_CONV_XCD=0: force the plain striding for A/B runs
+  return wgs;
+}
+
 template <typename T, int NT, bool HALO, bool RESIDENT>
 int launch(const ConvP& p, int nslabs, hipStream_t stream) {
   const size_t patch = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW;
@@ -696,11 +734,7 @@ int launch(const ConvP& p, int nslabs, hipStream_t stream) {
     if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
   }
   const int per_cu = (int)((160 * 1024) / lds) >= 2 ? 2 : 1;   // two resident workgroups overlap each other's memory phases
-  long wgs = (long)g_num_cus * per_cu;
-  wgs = wgs / p.nblk * p.nblk;                              // a multiple of the channel-block count
-  if (wgs < p.nblk) wgs = p.nblk;
-  const long need = (long)p.total_tiles * p.nblk;
-  if (wgs > need) wgs = need;
+  long wgs = grid_size((long)g_num_cus * per_cu, p);
   hipLaunchKernelGGL((conv_igemm_kernel<T, NT, HALO, RESIDENT>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -719,11 +753,7 @@ int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
   }
-  long wgs = (long)g_num_cus;
-  wgs = wgs / p.nblk * p.nblk;
-  if (wgs < p.nblk) wgs = p.nblk;
-  const long need = (long)p.total_tiles * p.nblk;
-  if (wgs > need) wgs = need;
+  long wgs = grid_size((long)g_num_cus, p);
   hipLaunchKernelGGL((conv_igemm_ws_kernel<NT, HALO>), dim3((unsigned)wgs), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;

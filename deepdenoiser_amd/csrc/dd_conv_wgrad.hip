@@ -23,6 +23,20 @@
 
 #include "dd_common.h"
 
+#ifdef DD_PROFILE_PHASES
+__device__ unsigned long long dd_wphase_cycles[16];
+#define WPHASE_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define WPHASE_ADD(i, a, b) if (blockIdx.x == 0 && threadIdx.x == 0) dd_wphase_cycles[i] += (b) - (a)
+extern "C" int dd_debug_wphases(unsigned long long* out16, int reset) {
+  if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dd_wphase_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_wphase_cycles), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define WPHASE_T(var)
+#define WPHASE_ADD(i, a, b)
+#endif
+
 namespace {
 
 struct WgradP {
@@ -155,6 +169,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
   const T* __restrict__ Q = reinterpret_cast<const T*>(a.q);
   const bool bias_q = a.bias_mode == 1 && ms == 0, bias_p = a.bias_mode == 2 && ns == 0;
 
+#ifdef DD_PROFILE_PHASES
+  const unsigned long long k_t0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
+#endif
   TilePlan<PH> pplan;
   TilePlan<DD_TILE> qplan;
   tile_plan<PH>(pplan, tid);
@@ -169,47 +186,67 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
 
   const int per_img = a.tiles_y * a.tiles_x;
   const int total_tiles = a.B * per_img;
+  uint4 qreg[TilePlan<DD_TILE>::ITERS];
+  uint4 preg[HALO ? TilePlan<PH>::ITERS : 1];
+  // global loads of one pixel tile (dy tile + haloed x tile) into registers; issued one tile AHEAD of its use, so the memory round
+  // trip (2-3 us on the loaded machine) overlaps the previous tile's 288 MFMAs instead of sitting in front of them
+  auto load_tile = [&](int tile) {
+    const int b = tile / per_img;
+    const int rem = tile - b * per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int y0 = ty * DD_TILE, x0 = tx * DD_TILE;
+    tile_load<T, DD_TILE>(qreg, qplan, Q, (long)b * a.H * a.W, a.ldq, a.nv, ns * KC, y0, x0, a.H, a.W, 0, 1, 0, 0, a.H, a.W, tid);
+    if constexpr (HALO)
+      tile_load<T, PH>(preg, pplan, P, (long)b * a.hin * a.win, a.ldp, a.mv, ms * KC, y0 - 1, x0 - 1, a.H, a.W, 1, 1, 0, 0, a.hin, a.win, tid);
+  };
+  if (HALO && ks < total_tiles) load_tile(ks);
   for (int tile = ks; tile < total_tiles; tile += a.ksplit) {
     const int b = tile / per_img;
     const int rem = tile - b * per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * DD_TILE, x0 = tx * DD_TILE;
 
-    uint4 qreg[TilePlan<DD_TILE>::ITERS];
-    tile_load<T, DD_TILE>(qreg, qplan, Q, (long)b * a.H * a.W, a.ldq, a.nv, ns * KC, y0, x0, a.H, a.W, 0, 1, 0, 0, a.H, a.W, tid);
     if constexpr (HALO) {
-      uint4 preg[TilePlan<PH>::ITERS];
-      tile_load<T, PH>(preg, pplan, P, (long)b * a.hin * a.win, a.ldp, a.mv, ms * KC, y0 - 1, x0 - 1, a.H, a.W, 1, 1, 0, 0, a.hin, a.win, tid);
+      WPHASE_T(w0);
       __syncthreads();  // previous tile fully consumed
       if (bias_q) bias_accumulate<T, DD_TILE>(bsum, qreg, qplan, false);
       if (bias_p) bias_accumulate<T, PH>(bsum, preg, pplan, true);
       tile_store<T, DD_TILE>(qtile, qreg, qplan, false);
       tile_store<T, PH>(ptile, preg, pplan, in_relu);
       __syncthreads();
+      WPHASE_T(w1);
+      if (tile + a.ksplit < total_tiles) load_tile(tile + a.ksplit);
+      WPHASE_T(w2);
+      WPHASE_ADD(0, w0, w1); WPHASE_ADD(1, w1, w2); WPHASE_ADD(5, 0ull, 1ull);
       if constexpr (BF) {
-        // 72 steps (8 k-steps x 9 taps) of 4 MFMAs, fully unrolled; the two transpose reads of the NEXT step's P fragment
-        // (and, spread over taps 0..3, of the next k-step's Q fragments) are issued ahead of each MFMA group and the
-        // interleave is pinned (the compiler otherwise sinks the reads in front of their MFMAs behind lgkmcnt(0)).
-        uint4 bq[2][NPW], ap[2];
+        // 72 steps (8 k-steps x 9 taps) of 4 MFMAs, fully unrolled.  The x fragment of step s+2 (two transpose reads) and, during
+        // taps 0..3, one dy fragment of the next k-step are issued in front of the MFMAs of step s; sched_barrier(0) pins exactly
+        // that order (sched_group_barrier only pins counts: the compiler then picks reads that are needed 4 MFMAs later).
+        constexpr int NSTEP = 8 * TAPS;
+        uint4 bq[2][NPW], ap[3];
+        auto p_frag = [&](int step) {
+          const int kst = step / TAPS, t = step - kst * TAPS;
+          return frag_tr_bf16(ptile, 2 * kst + t / 3, PW, t % 3, mi, lane);
+        };
 #pragma unroll
         for (int j = 0; j < NPW; ++j) bq[0][j] = frag_tr_bf16(qtile, 0, DD_TILE, 0, ni0 + j, lane);
-        ap[0] = frag_tr_bf16(ptile, 0, PW, 0, mi, lane);
+        ap[0] = p_frag(0);
+        ap[1] = p_frag(1);
 #pragma unroll
         for (int kst = 0; kst < 8; ++kst) {
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
             const int step = kst * TAPS + t;
-            int nds = 0;
-            if (t + 1 < TAPS) { ap[(step + 1) & 1] = frag_tr_bf16(ptile, 2 * kst + (t + 1) / 3, PW, (t + 1) % 3, mi, lane); nds += 2; }
-            else if (kst + 1 < 8) { ap[(step + 1) & 1] = frag_tr_bf16(ptile, 2 * (kst + 1), PW, 0, mi, lane); nds += 2; }
-            if (t < NPW && kst + 1 < 8) { bq[(kst + 1) & 1][t] = frag_tr_bf16(qtile, 2 * (kst + 1), DD_TILE, 0, ni0 + t, lane); nds += 2; }
+            if (step + 2 < NSTEP) ap[(step + 2) % 3] = p_frag(step + 2);
+            if (t < NPW && kst + 1 < 8) bq[(kst + 1) & 1][t] = frag_tr_bf16(qtile, 2 * (kst + 1), DD_TILE, 0, ni0 + t, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[step & 1], bq[kst & 1][j], acc[t][j]);
-            if (nds == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            else if (nds == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NPW, 0);
+            for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[step % 3], bq[kst & 1][j], acc[t][j]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+        WPHASE_T(w3);
+        WPHASE_ADD(2, w2, w3);
       } else {
         const int kq = lane >> 4, li = lane & 15;
 #pragma unroll 2
@@ -224,6 +261,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
         }
       }
     } else {
+      tile_load<T, DD_TILE>(qreg, qplan, Q, (long)b * a.H * a.W, a.ldq, a.nv, ns * KC, y0, x0, a.H, a.W, 0, 1, 0, 0, a.H, a.W, tid);
       __syncthreads();  // previous tile fully consumed
       if (bias_q) bias_accumulate<T, DD_TILE>(bsum, qreg, qplan, false);
       tile_store<T, DD_TILE>(qtile, qreg, qplan, false);
@@ -260,6 +298,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
     }
   }
 
+  WPHASE_T(e0);
   // D[m][n]: lane holds n = lane&15, m = (lane>>4)*4 + e
   const int li = lane & 15, q4 = (lane >> 4) * 4;
 #pragma unroll
@@ -271,10 +310,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = ms * KC + mi * 16 + q4 + e;
+#ifdef DD_EXP_WG_ATOMIC
+        if (m < a.m) __hip_atomic_fetch_add(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
         if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e]);
+#endif
       }
     }
 
+  WPHASE_T(e1);
+  WPHASE_ADD(3, e0, e1);
+#ifdef DD_PROFILE_PHASES
+  if (blockIdx.x == 0 && tid == 0) { dd_wphase_cycles[14] += __builtin_readcyclecounter() - k_t0; dd_wphase_cycles[15] += wall_clock64() - k_w0; }
+#endif
   if (a.bias_mode != 0) {   // (uniform) reduce the 32 threads that share a 16-byte channel group, then one atomic per channel
     constexpr int PER16 = Elem<T>::PER16;
     __syncthreads();

@@ -132,6 +132,9 @@ class ParamStore:
 
     def load_list(self, tensors):
         """Copy a list of tensors (creation order) into the arena -- used to share weights with the oracle."""
+        if self.values is None:
+            raise RuntimeError("parameters are created when the first program is built: call Architecture.program(...) / "
+                               "Predictor.prepare(H, W) before load_list()")
         assert len(tensors) == len(self.params), (len(tensors), len(self.params))
         for p, t in zip(self.params, tensors):
             assert tuple(t.shape) == p.shape, (p.name, tuple(t.shape), p.shape)

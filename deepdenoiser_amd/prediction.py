@@ -23,6 +23,45 @@ class Predictor:
     def __init__(self, architecture, tile_size=128, tile_overlap_size=14, tiles_per_batch=16):
         self.arch, self.tile_size, self.tile_overlap_size, self.tiles_per_batch = architecture, tile_size, tile_overlap_size, tiles_per_batch
         self.lib = L.load()
+        self._plans = {}
+
+    def prepare(self, H, W):
+        """Build (and cache) the tile program for an HxW frame; the network parameters exist after this call, so weights are loaded
+        with `architecture.params.load_list(...)` between prepare() and predict_frame()."""
+        self._frame_plan(H, W)
+
+    def _frame_plan(self, H, W):
+        """Tile plan, gather indices and stitch tables of a frame size (cached: every frame of a sequence shares them)."""
+        key = (H, W)
+        if key in self._plans:
+            return self._plans[key]
+        dev = self.arch.device
+        plan = tile_plan(H, W, self.tile_size, self.tile_overlap_size)
+        T = plan.tile
+        Bt = min(self.tiles_per_batch, plan.count)
+        prog = self.arch.program(Bt, T, T)
+        NF = prog.NF
+        origins = plan.windows()                                                              # row-major (Prediction.py:380-382)
+        grid = [(hi, wi) for hi in range(plan.rows.count) for wi in range(plan.cols.count)]
+        ar = torch.arange(T, device=dev)
+        chunks = []
+        for start in range(0, plan.count, Bt):
+            ids = list(range(start, min(start + Bt, plan.count)))
+            pad = ids + [ids[-1]] * (Bt - len(ids))                                           # ragged last batch: repeat a tile, never stitched
+            yy = torch.tensor([origins[t][0] for t in pad], device=dev)[:, None, None] + ar[None, :, None]
+            xx = torch.tensor([origins[t][1] for t in pad], device=dev)[:, None, None] + ar[None, None, :]
+            table = (L.StitchEntry * (len(ids) * NF))()
+            n = 0
+            for f in range(NF):
+                for slot, ti in enumerate(ids):
+                    hi, wi = grid[ti]
+                    (cy0, cy1), (cx0, cx1) = plan.rows.crops[hi], plan.cols.crops[wi]
+                    table[n] = L.StitchEntry(f * Bt + slot, cy0, cy1, cx0, cx1, f, plan.rows.offsets[hi], plan.cols.offsets[wi])
+                    n += 1
+            tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+            chunks.append((yy, xx, tdev, n))
+        self._plans[key] = (plan, prog, chunks)
+        return self._plans[key]
 
     def predict_frame(self, features):
         """features: {'source_image/0/<Pass>': [H,W,C] float32 tensor} -> {'prediction/<Pass>': [H,W,C]} (+ 'Combined' if all passes exist)."""
@@ -31,38 +70,15 @@ class Predictor:
         names = arch.required_source_names()
         frame = {k: torch.as_tensor(features[k], dtype=torch.float32).to(dev) for k in names}
         H, W = frame[names[0]].shape[0], frame[names[0]].shape[1]
-        plan = tile_plan(H, W, self.tile_size, self.tile_overlap_size)
-        T = plan.tile
-        Bt = min(self.tiles_per_batch, plan.count)
-        prog = arch.program(Bt, T, T)
-        NF = prog.NF
+        plan, prog, chunks = self._frame_plan(H, W)
+        T, NF = plan.tile, prog.NF
         frames = torch.zeros((NF, H, W, 3), dtype=torch.float32, device=dev)
-        origins = plan.windows()
-        grid = [(hi, wi) for hi in range(plan.rows.count) for wi in range(plan.cols.count)]    # row-major
         prog.pack_weights()
         stream = prog.g.stream_ptr()
-        for start in range(0, plan.count, Bt):
-            chunk = list(range(start, min(start + Bt, plan.count)))
-            tiled = {}
-            for k in names:
-                src = frame[k]
-                buf = torch.zeros((Bt, T, T, src.shape[2]), dtype=torch.float32, device=dev)
-                for slot, ti in enumerate(chunk):
-                    y0, x0 = origins[ti]
-                    buf[slot] = src[y0:y0 + T, x0:x0 + T]
-                tiled[k] = buf
-            prog.set_inputs(tiled)
+        for yy, xx, tdev, n in chunks:
+            prog.set_inputs({k: frame[k][yy, xx] for k in names})        # one gather per pass: [Bt,T,T,C] halo tiles
             prog.forward(pack=False)
             tiles = prog.predictions[0]                                  # [NF*Bt, T, T, 3], feature-major
-            table = (L.StitchEntry * (len(chunk) * NF))()
-            n = 0
-            for f in range(NF):
-                for slot, ti in enumerate(chunk):
-                    hi, wi = grid[ti]
-                    (cy0, cy1), (cx0, cx1) = plan.rows.crops[hi], plan.cols.crops[wi]
-                    table[n] = L.StitchEntry(f * Bt + slot, cy0, cy1, cx0, cx1, f, plan.rows.offsets[hi], plan.cols.offsets[wi])
-                    n += 1
-            tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
             L.check(lib.dd_stitch(tiles.ptr, T, 3, frames.data_ptr(), H, W, 3, 3, tdev.data_ptr(), n, stream))
         out = {}
         for f in arch.feature_predictions:

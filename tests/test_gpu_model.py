@@ -195,3 +195,45 @@ def test_segmented_trainer_matches_plain_step(use_graph):
     d = (ref.params.values - seg.params.values).abs()
     assert float(d.max()) <= 2 * 4 * lr
     assert float((d > 0.5 * lr).float().mean()) < 0.02
+
+
+def test_predictor_full_frame_matches_oracle_tiling():
+    """Prediction path: halo tiling -> batched forward -> device crop/stitch, against the literal restatement of
+    Prediction.py:259-311,380-441 driving the oracle network tile by tile.  Ragged last batch (24 tiles, 7 per batch)."""
+    _need_gpu()
+    import numpy as np
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.prediction import Predictor
+    from oracle import tiling_ref
+    aj = configs.architecture(filters=(16, 24), convs=1, flag_mode="NONE",
+                              combined={"Emission": {"Color": "Emission", "Direct": "", "Indirect": ""}})
+    H, W, T, O = 150, 214, 48, 6
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    arch = Architecture(aj, device="cuda", dtype="f32")
+    pred = Predictor(arch, tile_size=T, tile_overlap_size=O, tiles_per_batch=7)
+    pred.prepare(H, W)                                   # builds the tile program => creates the parameters
+    oracle.predict(_inputs(oracle, 1, T, T)[0])          # the oracle creates its variables on first use (TF scope semantics)
+    assert [p.name for p in arch.params.params] == list(oracle.vs.vars.keys())
+    arch.params.load_list(list(oracle.vs.vars.values()))
+    g = torch.Generator().manual_seed(3)
+    frame = {}
+    for f in oracle.features + oracle.auxiliary:
+        v = torch.randn(H, W, f.channels, generator=g)
+        frame[Naming.source_feature_name(f.name, index=0)] = v if f.name == "Normal" else v.abs()
+    out = pred.predict_frame(frame)
+    torch.cuda.synchronize()
+    t, o, hc, wc, windows = tiling_ref.plan(H, W, T, O)
+    assert (t, o) == (T, O) and hc * wc == 24
+    key = Naming.feature_prediction_name("Emission")
+    rows = []
+    for hi in range(hc):
+        row = []
+        for wi in range(wc):
+            lh, uh, lw, uw = windows[hi][wi]
+            tile = {k: v[None, lh:uh, lw:uw] for k, v in frame.items()}
+            row.append(oracle.predict(tile)[0][key][0].detach().numpy())
+        rows.append(row)
+    want = torch.from_numpy(np.asarray(tiling_ref.stitch(rows, H, W, T, O)))
+    got = out[key].cpu().double()
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 1e-4, rel_l2(got, want)

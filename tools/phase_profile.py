@@ -26,6 +26,25 @@ x = g.tensor(B, H, W, cin, relu=True, requires_grad=True); x.buf.normal_()
 lay = g.layer("b/conv2d", k, cin, cout)
 y = g.conv(x, lay, relu=True); y.mark_grad_written(); g.build_backward(); g.finalize(); y.grad().buf.normal_()
 s = g.stream_ptr(); g.run(g.pack_ops)
+wgrad = len(args) > 6 and args[6] == "wgrad"
+if wgrad:
+    lib.dd_debug_wphases.argtypes = [C.c_void_p, C.c_int]
+    op = [o for o in g.bwd_ops if getattr(o, "tag", "") == "conv_wgrad"][0]
+    op(s); torch.cuda.synchronize()
+    lib.dd_debug_wphases(None, 1)
+    n = 5
+    for _ in range(n):
+        op(s)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    lib.dd_debug_wphases(buf, 0)
+    units = buf[5] or 1
+    print("wgrad tiles per launch (block 0):", units / n)
+    print("block 0, whole kernel: %.0f ticks, %.2f us by the 100 MHz wall clock" % (buf[14] / n, buf[15] / n / 100.0))
+    for i, nm in [(0, "sync + tile -> LDS + sync"), (1, "issue next tile loads"), (2, "MFMA phase")]:
+        print("%-30s %9.0f cycles/tile" % (nm, buf[i] / units))
+    print("%-30s %9.0f cycles/launch" % ("epilogue atomics", buf[3] / n))
+    sys.exit(0)
 op = [o for o in (g.bwd_ops if dgrad else g.fwd_ops) if getattr(o, "tag", "") == "conv_igemm"][0]
 op(s); torch.cuda.synchronize()
 lib.dd_debug_phases(None, 1)
