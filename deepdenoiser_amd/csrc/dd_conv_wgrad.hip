@@ -89,6 +89,18 @@ __device__ __forceinline__ void tile_load(uint4 (&reg)[TilePlan<PH>::ITERS], con
     reg[it] = *reinterpret_cast<const uint4*>(ok ? base + ((long)gy * win + gx) * ld : zero);
   }
 }
+// one 16-byte vector of a stride-1 tile (no gather): the pieces of the NEXT tile are issued one at a time between the MFMA groups of
+// the current one, so the memory pipeline never backs up behind a burst of 19 loads per thread (a burst blocks the wave at issue
+// until the queue drains: ~4.5k cycles per tile, tools/phase_profile.py ... wgrad)
+template <typename T, int PH>
+__device__ __forceinline__ uint4 tile_load_one(int it, const TilePlan<PH>& pl, const T* __restrict__ base, bool live, int ld, int oy, int ox, int H, int W,
+                                               int halo, int win) {
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
+  const int yx = pl.yx[it];
+  const int ly = oy + (yx >> 8), lx = ox + (yx & 255);
+  const bool ok = live && yx >= 0 && ly >= -halo && lx >= -halo && ly < H + halo && lx < W + halo && ly >= 0 && lx >= 0 && ly < H && lx < W;
+  return *reinterpret_cast<const uint4*>(ok ? base + ((long)ly * win + lx) * ld : zero);
+}
 template <typename T, int PH>
 __device__ __forceinline__ void tile_store(char* lds, const uint4 (&reg)[TilePlan<PH>::ITERS], const TilePlan<PH>& pl, bool in_relu) {
 #pragma unroll
@@ -215,7 +227,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
       tile_store<T, PH>(ptile, preg, pplan, in_relu);
       __syncthreads();
       WPHASE_T(w1);
-      if (tile + a.ksplit < total_tiles) load_tile(tile + a.ksplit);
+      const int ntile = tile + a.ksplit;
+      if (!BF && ntile < total_tiles) load_tile(ntile);
       WPHASE_T(w2);
       WPHASE_ADD(0, w0, w1); WPHASE_ADD(1, w1, w2); WPHASE_ADD(5, 0ull, 1ull);
       if constexpr (BF) {
@@ -223,6 +236,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
         // taps 0..3, one dy fragment of the next k-step are issued in front of the MFMAs of step s; sched_barrier(0) pins exactly
         // that order (sched_group_barrier only pins counts: the compiler then picks reads that are needed 4 MFMAs later).
         constexpr int NSTEP = 8 * TAPS;
+        constexpr int QI = TilePlan<DD_TILE>::ITERS, PI = TilePlan<PH>::ITERS, EVERY = NSTEP / (QI + PI);
+        // next tile's origin and per-thread base pointers (channel group tid&7 of slice ns / ms)
+        const bool nlive = ntile < total_tiles;
+        const int nt = nlive ? ntile : tile;
+        const int nb = nt / per_img, nrem = nt - nb * per_img;
+        const int nty = nrem / a.tiles_x, ny0 = nty * DD_TILE, nx0 = (nrem - nty * a.tiles_x) * DD_TILE;
+        const int qch = ns * KC + (tid & 7) * Elem<T>::PER16, pch = ms * KC + (tid & 7) * Elem<T>::PER16;
+        const T* qbase = Q + (long)nb * a.H * a.W * a.ldq + qch;
+        const T* pbase = P + (long)nb * a.hin * a.win * a.ldp + pch;
+        const bool qlive = nlive && qch < a.nv, plive = nlive && pch < a.mv;
         uint4 bq[2][NPW], ap[3];
         auto p_frag = [&](int step) {
           const int kst = step / TAPS, t = step - kst * TAPS;
@@ -239,6 +262,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
             const int step = kst * TAPS + t;
             if (step + 2 < NSTEP) ap[(step + 2) % 3] = p_frag(step + 2);
             if (t < NPW && kst + 1 < 8) bq[(kst + 1) & 1][t] = frag_tr_bf16(qtile, 2 * (kst + 1), DD_TILE, 0, ni0 + t, lane);
+            if (step % EVERY == 0 && step / EVERY < QI + PI) {      // one global load of the next tile
+              constexpr int dummy = 0; (void)dummy;
+              const int k = step / EVERY;
+              if (k < QI) qreg[k] = tile_load_one<T, DD_TILE>(k, qplan, qbase, qlive, a.ldq, ny0, nx0, a.H, a.W, 0, a.W);
+              else preg[k - QI] = tile_load_one<T, PH>(k - QI, pplan, pbase, plive, a.ldp, ny0 - 1, nx0 - 1, a.H, a.W, 1, a.win);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[step % 3], bq[kst & 1][j], acc[t][j]);
@@ -340,6 +369,207 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// bf16 3x3 weight gradient, LDS-DMA variant (the hot one).  The pixel tiles go global -> LDS with global_load_lds_dwordx4 (1 KiB per
+// wave-instruction, no staging registers, no ds_write phase) into a DOUBLE-buffered LDS image; the 19 DMA pieces of the next tile
+// are issued one at a time between the MFMA groups of the current tile.  What this replaces, per 256-pixel tile (tools/phase_profile.py
+// ... wgrad, 64->64): 4.6k cycles blocked issuing 19 register loads + 3.3k cycles of ds_write staging in front of 6.6k cycles of MFMA,
+// and 76 staging VGPRs that pushed the 144 accumulator registers into AGPR shuffling.
+// An LDS-DMA chunk is 64 lanes x 16 B contiguous in LDS = 8 pixel rows of 128 B.  Lane l owns pixel (l >> 3) of the chunk and PHYSICAL
+// slot l & 7; the image is slot-swizzled by the pixel index (wg_off), and the chunk starts at a multiple of 8 pixels, so the lane always
+// fetches LOGICAL slot (l & 7) ^ (l >> 3): the swizzle is applied on the global side and the DMA stays a linear 1 KiB copy.
+// The DMA is issued through inline asm: with the builtin, hipcc puts s_waitcnt vmcnt(0) in front of every later ds_read (it cannot
+// tell the LDS regions apart), which would serialise exactly what this kernel overlaps.  Completion is awaited explicitly (vmcnt(0)
+// + barrier) once per tile.
+__device__ __forceinline__ void dma_1k(const void* gptr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory");
+}
+
+constexpr int WG_PCH = 41;                        // 1 KiB chunks of the 18x18 x tile (324 pixels -> 40.5)
+constexpr int WG_P_BYTES = WG_PCH * 1024, WG_Q_BYTES = DD_TILE * DD_TILE * DD_LDS_ROW, WG_BUF = WG_P_BYTES + WG_Q_BYTES;
+
+// 8 waves, 2 per SIMD: wave w computes input-channel tile (w & 3) x output-channel tiles {2*(w>>2), 2*(w>>2)+1} x 9 taps (72
+// accumulator registers).  With ONE wave per SIMD every s_waitcnt and every address instruction delays the next MFMA (in-order issue):
+// the 72-step loop measured 9.8k cycles per tile against 4.6k of pure MFMA time even without the DMA pieces; two waves per SIMD fill
+// each other's gaps.
+template <bool IN_RELU>
+__global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using T = bf16_t;
+  constexpr int TAPS = 9, KC = 64, NPW = 2, PW = DD_TILE + 2;
+  constexpr int QPC = 4, PPC = 6;                  // DMA pieces per wave and tile: 32 dy chunks / 8 waves, ceil(41 x chunks / 8)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int ns = bid % a.nslices; bid /= a.nslices;
+  const int ms = bid % a.mslices; bid /= a.mslices;
+  const int ks = bid;
+  const int mi = wave & 3, nj = (wave >> 2) * NPW;
+  const T* __restrict__ P = reinterpret_cast<const T*>(a.p);
+  const T* __restrict__ Q = reinterpret_cast<const T*>(a.q);
+  const bool bias_q = a.bias_mode == 1 && ms == 0;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#ifdef DD_PROFILE_PHASES
+  const unsigned long long k_t0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
+#endif
+
+  // this lane's part of every chunk: pixel r of the chunk, logical channel slot ls
+  const int r = lane >> 3, ls = (lane & 7) ^ r;
+  const int qch = ns * KC + ls * 8, pch = ms * KC + ls * 8;
+  const bool q_ok = qch < a.nv, p_ok = pch < a.mv;
+  const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
+  const int per_img = a.tiles_y * a.tiles_x;
+  const int total_tiles = a.B * per_img;
+  // per-lane, tile-invariant part of the DMA source addresses (byte offsets from the tile's origin pixel)
+  int q_off[2];                 // dy chunk c = wave*4 + k: tile row c >> 1, pixels (c & 1)*8 + r
+#pragma unroll
+  for (int h = 0; h < 2; ++h) q_off[h] = ((h * 8 + r) * a.ldq + qch) * 2;
+  int p_off[PPC], p_yx[PPC];    // x chunk c = k*8 + wave: pixel c*8 + r of the 18x18 haloed tile
+#pragma unroll
+  for (int k = 0; k < PPC; ++k) {
+    const int pix = (k * 8 + wave) * 8 + r;
+    const int py = (pix * 3641) >> 16, px = pix - py * PW;      // pix / 18 for pix < 400
+    p_off[k] = ((py * a.win + px) * a.ldp + pch) * 2;
+    p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (255 << 8);     // dummy pixels of the last chunk: always out of range
+  }
+
+  struct Origin { const char* q; const char* p; int y0, x0; bool live; };
+  auto origin = [&](int tile) {
+    Origin o;
+    o.live = tile < total_tiles;
+    const int t = o.live ? tile : 0;
+    const int b = t / per_img, rem = t - b * per_img;
+    const int ty = rem / a.tiles_x;
+    o.y0 = ty * DD_TILE; o.x0 = (rem - ty * a.tiles_x) * DD_TILE;
+    o.q = reinterpret_cast<const char*>(Q + ((long)b * a.H * a.W + (long)o.y0 * a.W + o.x0) * a.ldq);
+    o.p = reinterpret_cast<const char*>(P + ((long)b * a.hin * a.win + (long)(o.y0 - 1) * a.win + (o.x0 - 1)) * a.ldp);
+    return o;
+  };
+  // DMA piece k of the tile at `o` into buffer `sel`: k < QPC -> dy chunk, else x chunk
+  auto piece = [&](int k, const Origin& o, int sel) {
+    const unsigned buf = lds_base + sel * WG_BUF;
+    if (k < QPC) {
+      const int c = wave * QPC + k, row = c >> 1, h = c & 1;
+      const bool ok = o.live && q_ok && o.y0 + row < a.H && o.x0 + h * 8 + r < a.W;
+      dma_1k(ok ? o.q + (long)row * a.W * a.ldq * 2 + q_off[h] : zero, buf + WG_P_BYTES + c * 1024);
+    } else {
+      const int kk = k - QPC, c = kk * 8 + wave;
+      if (c < WG_PCH) {      // wave-uniform
+        const int gy = o.y0 - 1 + (p_yx[kk] >> 8), gx = o.x0 - 1 + (p_yx[kk] & 255);
+        const bool ok = o.live && p_ok && (unsigned)gy < (unsigned)a.hin && (unsigned)gx < (unsigned)a.win;
+        dma_1k(ok ? o.p + p_off[kk] : zero, buf + c * 1024);
+      }
+    }
+  };
+
+  f32x4_t acc[TAPS][NPW];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;     // dy column sum of channel ((wave & 3)*16 + lane&15) over this lane's pixels (waves 0-3 only)
+
+  {
+    const Origin o0 = origin(ks);
+#pragma unroll
+    for (int k = 0; k < QPC + PPC; ++k) piece(k, o0, 0);
+  }
+  int sel = 0;
+  for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+    WPHASE_T(w0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
+    __syncthreads();                      // ... and everyone's; buffer sel^1 is free (all waves finished the previous tile)
+    WPHASE_T(w1);
+    const Origin on = origin(tile + a.ksplit);
+    const char* ptile = smem + sel * WG_BUF;
+    const char* qtile = ptile + WG_P_BYTES;
+    // 72 steps = 4 runtime iterations x (2 k-steps x 9 taps, unrolled).  Four tile rows further down the swizzle key repeats
+    // ((y*18 + x) & 7 is periodic in y with period 4), so the fragment addresses of iteration kp are those of iteration 0 plus
+    // kp * 4 rows: a few dozen address registers instead of one per step.
+    constexpr int HSTEP = 2 * TAPS, PADV = 4 * PW * DD_LDS_ROW, QADV = 4 * DD_TILE * DD_LDS_ROW;
+    uint4 bq[2][NPW], ap[3];
+    auto p_frag = [&](const char* pt, int hs) {      // hs = step within the iteration (may run 1-2 steps into the next one)
+      const int k2 = hs / TAPS, t = hs - k2 * TAPS;
+      uint4 v = frag_tr_bf16(pt, 2 * k2 + t / 3, PW, t % 3, mi, lane);
+      if (IN_RELU) v = relu16<T>(v);
+      return v;
+    };
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) bq[0][j] = frag_tr_bf16(qtile, 0, DD_TILE, 0, nj + j, lane);
+    ap[0] = p_frag(ptile, 0);
+    ap[1] = p_frag(ptile, 1);
+#pragma unroll 1
+    for (int kp = 0; kp < 4; ++kp) {
+      const char* pt = ptile + kp * PADV;
+      const char* qt = qtile + kp * QADV;
+#pragma unroll
+      for (int hs = 0; hs < HSTEP; ++hs) {
+        const int k2 = hs / TAPS, t = hs - k2 * TAPS;
+        ap[(hs + 2) % 3] = p_frag(pt, hs + 2);                     // the last two of the tile read past it: never used
+        if (t < NPW) bq[(k2 + 1) & 1][t] = frag_tr_bf16(qt, 2 * (k2 + 1), DD_TILE, 0, nj + t, lane);
+#ifndef DD_EXP_NO_PIECE
+        if (hs % 6 == 2) {                                         // 3 pieces per iteration: 12 slots for the 10 pieces of the next tile
+          const int k = kp * 3 + hs / 6;
+          if (k < QPC + PPC) piece(k, on, sel ^ 1);
+        }
+#endif
+        if (t == 4 && bias_q && wave < 4) {      // bias gradient: wave w sums n-tile w (its own read: indexing bq by `wave` would spill it)
+          const uint4 v = frag_tr_bf16(qt, 2 * k2, DD_TILE, 0, wave, lane);      // 8 pixels of channel lane&15
+          float f[8];
+          unpack8(v, f);
+          bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[hs % 3], bq[k2 & 1][j], acc[t][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    WPHASE_T(w3);
+    WPHASE_ADD(0, w0, w1); WPHASE_ADD(2, w1, w3); WPHASE_ADD(5, 0ull, 1ull);
+  }
+
+  WPHASE_T(e0);
+  const int li = lane & 15, q4 = (lane >> 4) * 4;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int n = ns * KC + (nj + j) * 16 + li;
+      if (n >= a.n) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = ms * KC + mi * 16 + q4 + e;
+        if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e]);
+      }
+    }
+  if (a.bias_mode == 1) {
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    const int c = ns * KC + (wave & 3) * 16 + li;
+    if (bias_q && wave < 4 && lane < 16 && c < a.n) atomicAdd(a.bias_out + c, bsum);
+  }
+  WPHASE_T(e1);
+  WPHASE_ADD(3, e0, e1);
+#ifdef DD_PROFILE_PHASES
+  if (blockIdx.x == 0 && tid == 0) { dd_wphase_cycles[14] += __builtin_readcyclecounter() - k_t0; dd_wphase_cycles[15] += wall_clock64() - k_w0; }
+#endif
+}
+
+static int launch_dma(const WgradP& p, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)WG_BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long blocks = (long)p.ksplit * p.mslices * p.nslices;
+  if (p.flags & DD_IN_RELU) hipLaunchKernelGGL((wgrad_dma_kernel<true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL((wgrad_dma_kernel<false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 template <typename T, int TAPS>
 int launch(const WgradP& p, hipStream_t stream) {
   constexpr int PH = (TAPS == 9) ? DD_TILE + 2 : DD_TILE;
@@ -355,8 +585,15 @@ int launch(const WgradP& p, hipStream_t stream) {
   return DD_OK;
 }
 
+static bool dma_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DD_WGRAD_DMA"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 template <typename T>
 int dispatch(const WgradP& p, hipStream_t stream) {
+  if (sizeof(T) == 2 && p.taps == 9 && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && dma_enabled()) return launch_dma(p, stream);
   switch (p.taps) {
     case 9: return launch<T, 9>(p, stream);
     case 4: return launch<T, 4>(p, stream);

@@ -41,7 +41,7 @@ if wgrad:
     units = buf[5] or 1
     print("wgrad tiles per launch (block 0):", units / n)
     print("block 0, whole kernel: %.0f ticks, %.2f us by the 100 MHz wall clock" % (buf[14] / n, buf[15] / n / 100.0))
-    for i, nm in [(0, "sync + tile -> LDS + sync"), (1, "issue next tile loads"), (2, "MFMA phase")]:
+    for i, nm in [(0, "sync (+ tile -> LDS)"), (1, "issue next tile loads"), (2, "MFMA phase (+ DMA issue)")]:
         print("%-30s %9.0f cycles/tile" % (nm, buf[i] / units))
     print("%-30s %9.0f cycles/launch" % ("epilogue atomics", buf[3] / n))
     sys.exit(0)
