@@ -111,8 +111,25 @@ __device__ __forceinline__ void patch_load(uint4 (&reg)[PatchDim<HALO>::ITERS], 
     const int mul = ch_ok ? 1 : 0;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) reg[it] = *reinterpret_cast<const uint4*>(base + (pl.yx[it] >= 0 ? pl.rel[it] * mul : 0));
+  } else if (!gather) {
+    // Edge tile: ALL addresses first (out-of-image vectors -> the zero page), then the loads back to back.  Computing each address right
+    // before its load lets hipcc reuse the destination registers of loads still in flight as address temporaries, and every such reuse
+    // is an s_waitcnt vmcnt() on the older loads AND stores (gfx9 counts stores in vmcnt): the edge tiles then pay a memory round trip
+    // per vector, and with a static tile assignment the slowest (all-edge) workgroup sets the launch time.
+    const T* base = X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch;      // may point outside the image; only valid vectors use it
+    const T* ptr[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int yx = pl.yx[it];
+      const bool ok = yx >= 0 && ch_ok && (unsigned)(oy + (yx >> 8)) < (unsigned)p.hin && (unsigned)(ox + (yx & 255)) < (unsigned)p.win;
+      ptr[it] = ok ? base + pl.rel[it] : zero;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) reg[it] = *reinterpret_cast<const uint4*>(ptr[it]);
+    __builtin_amdgcn_sched_barrier(0);
   } else {
-    const int sy = gather ? 2 : 1, ay = gather ? (tap >> 1) : 0, ax = gather ? (tap & 1) : 0;
+    const int sy = 2, ay = tap >> 1, ax = tap & 1;
     const T* base = X + (long)tc.b * p.hin * p.win * p.ldx + ch;
     const int ylo = HALO ? -1 : 0, yhi = p.H + (HALO ? 1 : 0), xhi = p.W + (HALO ? 1 : 0);
 #pragma unroll
@@ -676,6 +693,10 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       const int nnch = min(2, p.kchunks - 2 * nslice);
       PHASE_T(i0);
 #ifndef DD_EXP_NO_IO
+      // dgrad (mask fused into the drain): drain FIRST.  Loads return in order, so mask loads issued behind the next patch's loads make
+      // the drain wait for the whole patch; the patch loads still land well before the MFMA waves reach the barrier.
+      const bool drain_first = M != nullptr && pending >= 0;
+      if (drain_first) { drain(pending); pending = -1; }
       if (has_next) patch_load<T, HALO>(pre, plan, X, p, ntile, nslice, ntap0, nnch * 4, t256);
 #endif
       PHASE_T(i1);
