@@ -44,6 +44,7 @@ struct WgradP {
   int ldp, m, ldq, n, mv, nv;   // mv/nv: staged (16-byte rounded) channel counts
   int B, H, W, taps, flags, bias_mode;
   int tiles_x, tiles_y, ksplit, mslices, nslices;
+  int ncombo, cstart[33];       // LDS-DMA kernel: workgroups [cstart[c], cstart[c+1]) split the pixel tiles of (ms, ns) = (c / nslices, c % nslices)
   int hin, win;
 };
 
@@ -399,11 +400,13 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   constexpr int TAPS = 9, KC = 64, NPW = 2, PW = DD_TILE + 2;
   constexpr int QPC = 4, PPC = 6;                  // DMA pieces per wave and tile: 32 dy chunks / 8 waves, ceil(41 x chunks / 8)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
-  const int ns = bid % a.nslices; bid /= a.nslices;
-  const int ms = bid % a.mslices; bid /= a.mslices;
-  const int ks = bid;
+  // (channel-slice pair, split index): slices with fewer valid channel tiles get fewer workgroups (they finish their tiles faster)
+  int combo = 0;
+  while (combo + 1 < a.ncombo && (int)blockIdx.x >= a.cstart[combo + 1]) ++combo;
+  const int ks = blockIdx.x - a.cstart[combo], ksplit = a.cstart[combo + 1] - a.cstart[combo];
+  const int ms = combo / a.nslices, ns = combo - ms * a.nslices;
   const int mi = wave & 3, nj = (wave >> 2) * NPW;
+  const bool active = mi * 16 < a.m - ms * KC && nj * 16 < a.n - ns * KC;   // this wave's channel tiles exist (24-channel layers: 2 of 8 waves)
   const T* __restrict__ P = reinterpret_cast<const T*>(a.p);
   const T* __restrict__ Q = reinterpret_cast<const T*>(a.q);
   const bool bias_q = a.bias_mode == 1 && ms == 0;
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int j = 0; j < NPW; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;     // dy column sum of channel ((wave & 3)*16 + lane&15) over this lane's pixels (waves 0-3 only)
+  float bsum[NPW] = {0.f, 0.f};     // dy column sums of channels (nj + jj)*16 + lane&15 over this lane's pixels (the mi == 0 waves)
 
   {
     const Origin o0 = origin(ks);
@@ -474,12 +477,17 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
     for (int k = 0; k < QPC + PPC; ++k) piece(k, o0, 0);
   }
   int sel = 0;
-  for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+  for (int tile = ks; tile < total_tiles; tile += ksplit, sel ^= 1) {
     WPHASE_T(w0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
     __syncthreads();                      // ... and everyone's; buffer sel^1 is free (all waves finished the previous tile)
     WPHASE_T(w1);
-    const Origin on = origin(tile + a.ksplit);
+    const Origin on = origin(tile + ksplit);
+    if (!active) {      // nothing to multiply: keep feeding the pipeline
+#pragma unroll
+      for (int k = 0; k < QPC + PPC; ++k) piece(k, on, sel ^ 1);
+      continue;
+    }
     const char* ptile = smem + sel * WG_BUF;
     const char* qtile = ptile + WG_P_BYTES;
     // 72 steps = 4 runtime iterations x (2 k-steps x 9 taps, unrolled).  Four tile rows further down the swizzle key repeats
@@ -512,11 +520,13 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
           if (k < QPC + PPC) piece(k, on, sel ^ 1);
         }
 #endif
-        if (t == 4 && bias_q && wave < 4) {      // bias gradient: wave w sums n-tile w (its own read: indexing bq by `wave` would spill it)
-          const uint4 v = frag_tr_bf16(qt, 2 * k2, DD_TILE, 0, wave, lane);      // 8 pixels of channel lane&15
-          float f[8];
-          unpack8(v, f);
-          bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        if (t == 4 && bias_q && mi == 0) {       // bias gradient: the first input-channel wave of each n-half sums its dy fragments
+#pragma unroll
+          for (int jj = 0; jj < NPW; ++jj) {      // bq[k2 & 1][jj]: 8 pixels of channel lane&15 of n-tile nj + jj
+            float f[8];
+            unpack8(bq[k2 & 1][jj], f);
+            bsum[jj] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -543,10 +553,14 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
       }
     }
   if (a.bias_mode == 1) {
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    const int c = ns * KC + (wave & 3) * 16 + li;
-    if (bias_q && wave < 4 && lane < 16 && c < a.n) atomicAdd(a.bias_out + c, bsum);
+#pragma unroll
+    for (int jj = 0; jj < NPW; ++jj) {
+      float b = bsum[jj];
+      b += __shfl_xor(b, 16);
+      b += __shfl_xor(b, 32);
+      const int c = ns * KC + (nj + jj) * 16 + li;
+      if (bias_q && mi == 0 && lane < 16 && c < a.n) atomicAdd(a.bias_out + c, b);
+    }
   }
   WPHASE_T(e1);
   WPHASE_ADD(3, e0, e1);
@@ -555,7 +569,28 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 #endif
 }
 
-static int launch_dma(const WgradP& p, hipStream_t stream) {
+static int launch_dma(WgradP& p, hipStream_t stream) {
+  // Work split.  A workgroup's time per tile is set by its busiest SIMD = the number of n-halves (2 x 16 output channels) its slice has,
+  // plus a DMA/barrier floor: weight 3 for a full slice, 2 for a half one.  `target` workgroups in total (1 per CU).
+  const int nc = p.mslices * p.nslices;
+  const long total_tiles = (long)p.B * p.tiles_x * p.tiles_y;
+  const int target = p.ksplit * nc;
+  if (nc > 32) { dd_set_error("dd_conv_wgrad: more than 32 channel-slice pairs"); return DD_ERR_INVALID; }
+  int w[32], wsum = 0;
+  for (int c = 0; c < nc; ++c) {
+    const int ns = c % p.nslices;
+    const int nvalid = p.n - ns * 64 < 64 ? p.n - ns * 64 : 64;
+    w[c] = nvalid > 32 ? 3 : 2;
+    wsum += w[c];
+  }
+  p.ncombo = nc;
+  p.cstart[0] = 0;
+  for (int c = 0; c < nc; ++c) {
+    long k = (long)target * w[c] / wsum;
+    if (k < 1) k = 1;
+    if (k > total_tiles) k = total_tiles;
+    p.cstart[c + 1] = p.cstart[c] + (int)k;
+  }
   const size_t lds = 2 * (size_t)WG_BUF;
   static bool attr_set = false;
   if (!attr_set) {
@@ -563,7 +598,7 @@ static int launch_dma(const WgradP& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const long blocks = (long)p.ksplit * p.mslices * p.nslices;
+  const long blocks = p.cstart[p.ncombo];
   if (p.flags & DD_IN_RELU) hipLaunchKernelGGL((wgrad_dma_kernel<true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   else hipLaunchKernelGGL((wgrad_dma_kernel<false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
@@ -593,7 +628,7 @@ static bool dma_enabled() {
 
 template <typename T>
 int dispatch(const WgradP& p, hipStream_t stream) {
-  if (sizeof(T) == 2 && p.taps == 9 && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && dma_enabled()) return launch_dma(p, stream);
+  if (sizeof(T) == 2 && p.taps == 9 && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && dma_enabled()) { WgradP q = p; return launch_dma(q, stream); }
   switch (p.taps) {
     case 9: return launch<T, 9>(p, stream);
     case 4: return launch<T, 4>(p, stream);
