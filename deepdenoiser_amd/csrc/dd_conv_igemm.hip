@@ -59,22 +59,29 @@ template <bool HALO> struct PatchDim {
 // Per-thread staging plan of a patch K-slice, computed ONCE per workgroup (the kernel is VALU-issue bound: per-vector index
 // arithmetic must not be repeated per tile).  Vector `it` of this thread covers patch pixel (py,px) = yx[it]; rel[it] is its
 // element offset from the patch origin pixel in the input image; lds[it] its byte offset in the LDS image.
+// A vector memory instruction costs the same issue time whether 3 or 8 of a pixel's 16-byte slots are real (the rest would read the
+// zero page), so narrow layers (K <= 32: one 64-byte chunk) use a COMPACT plan: 4 vectors per pixel instead of 8, half the instructions.
 template <bool HALO> struct PatchPlan {
   int yx[PatchDim<HALO>::ITERS];     // (py << 8) | px, or -1 when the vector is outside the patch
-  int rel[PatchDim<HALO>::ITERS];
+  int rel[PatchDim<HALO>::ITERS];    // element offset from the patch origin pixel, INCLUDING the vector's channel offset
   int lds[PatchDim<HALO>::ITERS];
+  int slot;                          // 16-byte slot of this thread's vectors within their pixel (256 % 8 == 0: the same for all)
+  int n_it;                          // vectors this thread really has (wave-uniform upper bound): the rest are skipped
 };
 
-template <bool HALO>
+template <typename T, bool HALO>
 __device__ __forceinline__ void patch_plan(PatchPlan<HALO>& pl, const ConvP& p, int tid) {
   constexpr int PH = PatchDim<HALO>::PH, NPIX = PatchDim<HALO>::NPIX, ITERS = PatchDim<HALO>::ITERS;
+  const bool compact = p.kchunks == 1;
+  pl.n_it = compact ? (NPIX * 4 + 255) / 256 : ITERS;
+  pl.slot = compact ? tid & 3 : tid & 7;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int i = tid + it * 256;
-    const int pix = i >> 3, slot = i & 7;
+    const int pix = compact ? i >> 2 : i >> 3, slot = compact ? i & 3 : i & 7;
     const int py = pix / PH, px = pix - py * PH;
     pl.yx[it] = pix < NPIX ? ((py << 8) | px) : -1;
-    pl.rel[it] = (py * p.win + px) * p.ldx;
+    pl.rel[it] = (py * p.win + px) * p.ldx + slot * Elem<T>::PER16;
     pl.lds[it] = lds_pix_off(py, px, PH, slot);
   }
 }
@@ -101,45 +108,47 @@ __device__ __forceinline__ void patch_load(uint4 (&reg)[PatchDim<HALO>::ITERS], 
   const TileCoord tc = tile_coord(p, tile);
   const int oy = tc.y0 - (HALO ? 1 : 0), ox = tc.x0 - (HALO ? 1 : 0);
   const bool gather = (p.flags & DD_GATHER2X2) != 0;
-  const int slot = tid & 7;
-  const int ch = slice * KC + slot * PER16;
-  const bool ch_ok = slot < nslots && ch < p.cin;
+  const int ch0 = slice * KC;
   const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
   const bool interior = !gather && oy >= 0 && ox >= 0 && oy + PH <= p.H && ox + PH <= p.W;
+  // vector `it` is real iff it lies in the patch and its channels exist: slot < nslots (this K-slice) and channel < cin
+  const bool slot_ok = pl.slot < nslots && ch0 + pl.slot * PER16 < p.cin;
+  auto vec_ok = [&](int it) { return slot_ok && pl.yx[it] >= 0; };
   if (interior) {
-    const T* base = ch_ok ? X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch : zero;
-    const int mul = ch_ok ? 1 : 0;
+    const T* base = X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch0;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) reg[it] = *reinterpret_cast<const uint4*>(base + (pl.yx[it] >= 0 ? pl.rel[it] * mul : 0));
+    for (int it = 0; it < ITERS; ++it)
+      if (it < pl.n_it) reg[it] = *reinterpret_cast<const uint4*>(vec_ok(it) ? base + pl.rel[it] : zero);
   } else if (!gather) {
     // Edge tile: ALL addresses first (out-of-image vectors -> the zero page), then the loads back to back.  Computing each address right
     // before its load lets hipcc reuse the destination registers of loads still in flight as address temporaries, and every such reuse
     // is an s_waitcnt vmcnt() on the older loads AND stores (gfx9 counts stores in vmcnt): the edge tiles then pay a memory round trip
     // per vector, and with a static tile assignment the slowest (all-edge) workgroup sets the launch time.
-    const T* base = X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch;      // may point outside the image; only valid vectors use it
+    const T* base = X + (((long)tc.b * p.hin + oy) * p.win + ox) * p.ldx + ch0;      // may point outside the image; only valid vectors use it
     const T* ptr[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int yx = pl.yx[it];
-      const bool ok = yx >= 0 && ch_ok && (unsigned)(oy + (yx >> 8)) < (unsigned)p.hin && (unsigned)(ox + (yx & 255)) < (unsigned)p.win;
+      const bool ok = vec_ok(it) && (unsigned)(oy + (yx >> 8)) < (unsigned)p.hin && (unsigned)(ox + (yx & 255)) < (unsigned)p.win;
       ptr[it] = ok ? base + pl.rel[it] : zero;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) reg[it] = *reinterpret_cast<const uint4*>(ptr[it]);
+    for (int it = 0; it < ITERS; ++it)
+      if (it < pl.n_it) reg[it] = *reinterpret_cast<const uint4*>(ptr[it]);
     __builtin_amdgcn_sched_barrier(0);
   } else {
     const int sy = 2, ay = tap >> 1, ax = tap & 1;
-    const T* base = X + (long)tc.b * p.hin * p.win * p.ldx + ch;
+    const T* base = X + (long)tc.b * p.hin * p.win * p.ldx + ch0;
     const int ylo = HALO ? -1 : 0, yhi = p.H + (HALO ? 1 : 0), xhi = p.W + (HALO ? 1 : 0);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int yx = pl.yx[it];
       const int ly = oy + (yx >> 8), lx = ox + (yx & 255);
       const int gy = ly * sy + ay, gx = lx * sy + ax;
-      const bool ok = yx >= 0 && ch_ok && ly >= ylo && lx >= ylo && ly < yhi && lx < xhi && gy >= 0 && gx >= 0 && gy < p.hin && gx < p.win;
-      const T* ptr = ok ? base + ((long)gy * p.win + gx) * p.ldx : zero;
-      reg[it] = *reinterpret_cast<const uint4*>(ptr);
+      const bool ok = vec_ok(it) && ly >= ylo && lx >= ylo && ly < yhi && lx < xhi && gy >= 0 && gx >= 0 && gy < p.hin && gx < p.win;
+      const T* ptr = ok ? base + ((long)gy * p.win + gx) * p.ldx + pl.slot * PER16 : zero;
+      if (it < pl.n_it) reg[it] = *reinterpret_cast<const uint4*>(ptr);
     }
   }
 }
@@ -150,7 +159,7 @@ __device__ __forceinline__ void patch_store(char* lds, const uint4 (&reg)[PatchD
   for (int it = 0; it < PatchDim<HALO>::ITERS; ++it) {
     uint4 v = reg[it];
     if (in_relu) v = relu16<T>(v);
-    if (pl.yx[it] >= 0) *reinterpret_cast<uint4*>(lds + pl.lds[it]) = v;
+    if (it < pl.n_it && pl.yx[it] >= 0) *reinterpret_cast<uint4*>(lds + pl.lds[it]) = v;
   }
 }
 
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
   }
   PatchPlan<HALO> plan;
-  patch_plan<HALO>(plan, p, tid);
+  patch_plan<T, HALO>(plan, p, tid);
 #ifdef DD_STAGGER
   // de-phase the workgroups: all CUs otherwise run load / MFMA / store phases in lockstep and HBM sees bursts
   for (int i = 0; i < (int)(blockIdx.x % DD_STAGGER); ++i) __builtin_amdgcn_s_sleep(DD_STAGGER_SLEEP);
@@ -621,17 +630,22 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
     PatchPlan<HALO> plan;
     uint4 pre[PatchDim<HALO>::ITERS];
     {
-      patch_plan<HALO>(plan, p, t256);
+      patch_plan<T, HALO>(plan, p, t256);
       patch_load<T, HALO>(pre, plan, X, p, first, 0, 0, min(2, p.kchunks) * 4, t256);
       patch_store<T, HALO>(patch, pre, plan, in_relu);
     }
     __syncthreads();
+    // Drain mapping: 2^sh 16-byte slots per pixel (8 = the full 64-channel row; narrow layers use fewer vectors per pixel, so a
+    // 24-channel output costs 4 store instructions per wave instead of 8 -- store issue time does not shrink with idle lanes).
     constexpr int ESLOTS = 8;
+    const int nsl_out = ((pixshuf ? NT * 16 : min(NT * 16, p.n - n0)) + 7) >> 3;
+    const int sh = pixshuf ? 3 : nsl_out > 4 ? 3 : nsl_out > 2 ? 2 : nsl_out > 1 ? 1 : 0;
+    const int e_n = 1 << sh;                 // store instructions per wave and tile
     int e_lds[ESLOTS], e_pix[ESLOTS];
-    const int e_slot = lane & 7;
+    const int e_slot = lane & (e_n - 1);
 #pragma unroll
     for (int it = 0; it < ESLOTS; ++it) {
-      const int pixl = (lane >> 3) + it * 8;
+      const int pixl = ((lane >> sh) + it * (64 >> sh)) & 63;
       e_lds[it] = lds_off(pixl, e_slot);
       const int tyl = w4 * 4 + (pixl >> 4), txl = pixl & 15;
       e_pix[it] = pixshuf ? (2 * tyl) * p.wout + 2 * txl : tyl * p.wout + txl;
@@ -647,13 +661,15 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       const long tile_pix = pixshuf ? ((long)tc.b * p.hout + 2 * tc.y0) * p.wout + 2 * tc.x0 : ((long)tc.b * p.hout + tc.y0) * p.wout + tc.x0;
 #pragma unroll
       for (int half = 0; half < ESLOTS; half += 4) {
+        if (half >= e_n) break;                 // wave-uniform
         uint4 pv[4], mv[4], rv[4], av[4];
         long pixv[4];
         bool okv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int it = half + k;
-          const int pixl = (lane >> 3) + it * 8;
+          if (it >= e_n) continue;              // wave-uniform (1 or 2 vectors per wave and tile)
+          const int pixl = ((lane >> sh) + it * (64 >> sh)) & 63;
           okv[k] = lane_ok && (interior || (tc.y0 + w4 * 4 + (pixl >> 4) < p.H && tc.x0 + (pixl & 15) < p.W));
           pixv[k] = okv[k] ? tile_pix + abpix + e_pix[it] : tile_pix;
           pv[k] = *reinterpret_cast<const uint4*>(stage + e_lds[it]);
@@ -663,6 +679,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          if (half + k >= e_n) continue;
           uint4 o4 = pv[k];
           if (R) {
             float v[8], t[8];
