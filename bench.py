@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="tile-passes per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="tile-passes per GPU per step")
     ap.add_argument("--tile", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
