@@ -110,7 +110,7 @@ def load():
     lib.dd_conv_igemm.argtypes = [C.POINTER(ConvArgs), vp]
     lib.dd_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
     lib.dd_colsum.argtypes = [vp, i, i, l, vp, i, vp]
-    lib.dd_maxpool_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
+    lib.dd_maxpool_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, i, vp]
     lib.dd_maxpool_bwd.argtypes = [vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.dd_avgpool.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
     lib.dd_prepare_feature.argtypes = [vp, i, vp, i, C.POINTER(FeatureParams), i, i, i, vp]

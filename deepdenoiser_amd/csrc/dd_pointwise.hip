@@ -102,44 +102,71 @@ __host__ __device__ inline void same_pad(int size, int k, int s, int* out, int* 
   *out = o; *before = total / 2;
 }
 
+// One thread = one output pixel x 16 bytes of channels (8 bf16 / 4 f32): 16-byte loads and stores, the argmax plane as 8 / 4 bytes.
+// relu_mask: the pooled tensor is a ReLU output whose backward mask (x > 0) is fused here -- a window whose maximum is not positive
+// records index 255 ("no gradient"), so the backward pass never has to read x again (42 % of its HBM traffic).
+template <typename T> struct Vec16 { static constexpr int N = Elem<T>::PER16; };
+template <typename T> __device__ __forceinline__ void vload(const T* p, float (&v)[Elem<T>::PER16]);
+template <> __device__ __forceinline__ void vload<float>(const float* p, float (&v)[4]) { load4<float>(p, v); }
+template <> __device__ __forceinline__ void vload<bf16_t>(const bf16_t* p, float (&v)[8]) { unpack8(*reinterpret_cast<const uint4*>(p), v); }
+template <typename T> __device__ __forceinline__ void vstore(T* p, const float (&v)[Elem<T>::PER16]);
+template <> __device__ __forceinline__ void vstore<float>(float* p, const float (&v)[4]) { store4<float>(p, v); }
+template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack8(v); }
+
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
-                                   int C, int B, int H, int W, int OH, int OW, int pool, int stride, int pby, int pbx) {
-  const int cg = C >> 2;
+                                   int C, int B, int H, int W, int OH, int OW, int pool, int stride, int pby, int pbx, int relu_mask) {
+  constexpr int N = Elem<T>::PER16;
+  const int cg = C / N;
   const long total = (long)B * OH * OW * cg;
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % cg) * 4;
+  const int c = (int)(i % cg) * N;
   long r = i / cg;
   const int ox = (int)(r % OW); r /= OW;
   const int oy = (int)(r % OH);
   const int b = (int)(r / OH);
-  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  int arg[4] = {0, 0, 0, 0};
+  float best[N];
+  int arg[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { best[e] = -INFINITY; arg[e] = 0; }
   for (int a = 0; a < pool; ++a)
     for (int bb = 0; bb < pool; ++bb) {
       const int sy = oy * stride + a - pby, sx = ox * stride + bb - pbx;
       if (sy < 0 || sx < 0 || sy >= H || sx >= W) continue;
-      float v[4];
-      load4<T>(x + (((long)b * H + sy) * W + sx) * ldx + c, v);
+      float v[N];
+      vload<T>(x + (((long)b * H + sy) * W + sx) * ldx + c, v);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < N; ++e)
         if (v[e] > best[e]) { best[e] = v[e]; arg[e] = a * pool + bb; }
     }
   const long opix = ((long)b * OH + oy) * OW + ox;
-  store4<T>(y + opix * ldy + c, best);
-  *reinterpret_cast<uchar4*>(idx + opix * C + c) = make_uchar4((uint8_t)arg[0], (uint8_t)arg[1], (uint8_t)arg[2], (uint8_t)arg[3]);
+  vstore<T>(y + opix * ldy + c, best);
+  uint32_t packed[N / 4];
+#pragma unroll
+  for (int w = 0; w < N / 4; ++w) {
+    packed[w] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = (relu_mask && !(best[w * 4 + e] > 0.f)) ? 255 : arg[w * 4 + e];
+      packed[w] |= (uint32_t)k << (8 * e);
+    }
+  }
+  if (N == 8) *reinterpret_cast<uint2*>(idx + opix * C + c) = make_uint2(packed[0], packed[N / 4 - 1]);
+  else *reinterpret_cast<uint32_t*>(idx + opix * C + c) = packed[0];
 }
 extern "C" int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
-                              int pool, int stride, int dtype, dd_stream stream) {
-  DD_REQUIRE(x && y && idx && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "dd_maxpool_fwd: C, ld must be multiples of 4");
+                              int pool, int stride, int relu_mask, int dtype, dd_stream stream) {
+  const int per16 = dtype == DD_F32 ? 4 : 8;
+  DD_REQUIRE(x && y && idx && C % per16 == 0 && ldx % per16 == 0 && ldy % per16 == 0, "dd_maxpool_fwd: C, ld must be multiples of %d", per16);
+  DD_REQUIRE(pool * pool < 255, "dd_maxpool_fwd: pool=%d too large", pool);
   int OH, OW, pby, pbx;
   same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
-  const long total = (long)B * OH * OW * (C / 4);
+  const long total = (long)B * OH * OW * (C / per16);
   if (dtype == DD_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)x, ldx, (float*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)x, ldx, (float*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx, relu_mask);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx, relu_mask);
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -148,55 +175,60 @@ template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int lddx,
                                    const T* __restrict__ mask, int ldmask, int C, int B, int H, int W, int OH, int OW,
                                    int pool, int stride, int pby, int pbx, int accumulate) {
-  const int cg = C >> 2;
+  constexpr int N = Elem<T>::PER16;
+  const int cg = C / N;
   const long total = (long)B * H * W * cg;
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % cg) * 4;
+  const int c = (int)(i % cg) * N;
   long r = i / cg;
   const int x = (int)(r % W); r /= W;
   const int y = (int)(r % H);
   const int b = (int)(r / H);
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  float g[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) g[e] = 0.f;
   // windows (oy, ox) that contain (y, x): oy*stride - pby <= y <= oy*stride - pby + pool - 1
   const int oy_hi = (y + pby) / stride, ox_hi = (x + pbx) / stride;
   for (int oy = oy_hi; oy >= 0 && oy * stride - pby + pool - 1 >= y; --oy) {
     if (oy >= OH) continue;
     for (int ox = ox_hi; ox >= 0 && ox * stride - pbx + pool - 1 >= x; --ox) {
       if (ox >= OW) continue;
-      const int k = (y - (oy * stride - pby)) * pool + (x - (ox * stride - pbx));
+      const uint32_t k = (uint32_t)((y - (oy * stride - pby)) * pool + (x - (ox * stride - pbx)));
       const long opix = ((long)b * OH + oy) * OW + ox;
-      const uchar4 a = *reinterpret_cast<const uchar4*>(idx + opix * C + c);
-      float v[4];
-      load4<T>(dy + opix * lddy + c, v);
-      if (a.x == k) g[0] += v[0];
-      if (a.y == k) g[1] += v[1];
-      if (a.z == k) g[2] += v[2];
-      if (a.w == k) g[3] += v[3];
+      uint32_t a[N / 4];
+      if (N == 8) { const uint2 t = *reinterpret_cast<const uint2*>(idx + opix * C + c); a[0] = t.x; a[N / 4 - 1] = t.y; }
+      else a[0] = *reinterpret_cast<const uint32_t*>(idx + opix * C + c);
+      float v[N];
+      vload<T>(dy + opix * lddy + c, v);
+#pragma unroll
+      for (int e = 0; e < N; ++e)
+        if (((a[e >> 2] >> (8 * (e & 3))) & 255u) == k) g[e] += v[e];
     }
   }
   const long pix = ((long)b * H + y) * W + x;
   if (mask) {
-    float m[4];
-    load4<T>(mask + pix * ldmask + c, m);
+    float m[N];
+    vload<T>(mask + pix * ldmask + c, m);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+    for (int e = 0; e < N; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
   }
   T* dst = dx + pix * lddx + c;
   if (accumulate) {
-    float o[4];
-    load4<T>(dst, o);
+    float o[N];
+    vload<T>(dst, o);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] += o[e];
+    for (int e = 0; e < N; ++e) g[e] += o[e];
   }
-  store4<T>(dst, g);
+  vstore<T>(dst, g);
 }
 extern "C" int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, const void* mask, int ldmask,
                               int C, int B, int H, int W, int pool, int stride, int accumulate, int dtype, dd_stream stream) {
-  DD_REQUIRE(dy && idx && dx && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "dd_maxpool_bwd: C, ld must be multiples of 4");
+  const int per16 = dtype == DD_F32 ? 4 : 8;
+  DD_REQUIRE(dy && idx && dx && C % per16 == 0 && lddy % per16 == 0 && lddx % per16 == 0, "dd_maxpool_bwd: C, ld must be multiples of %d", per16);
   int OH, OW, pby, pbx;
   same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
-  const long total = (long)B * H * W * (C / 4);
+  const long total = (long)B * H * W * (C / per16);
   if (dtype == DD_F32)
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dy, lddy, idx, (float*)dx, lddx, (const float*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate);
   else
@@ -237,30 +269,56 @@ __device__ __forceinline__ float standardize(float v, const dd_feature_params& f
   return (v - fp.mean) * fp.inv_std;
 }
 
-__global__ void prepare_feature_kernel(const float* __restrict__ src, int cs, float* __restrict__ dst, int ldd,
-                                       const dd_feature_params fp, int B, int H, int W) {
-  const long total = (long)B * H * W;
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int x = (int)(i % W);
-  const long r = i / W;
-  const int y = (int)(r % H);
-  const int b = (int)(r / H);
+// One workgroup = one 16x16 pixel tile.  The 18x18 haloed tile is staged in LDS ONCE (symmetric border indices resolved while staging),
+// standardised there, and the 3x3 (or plus-shaped) local variance is taken from LDS: one signed_log1p per pixel and channel instead of
+// up to nine, and no 27 scalar global loads per pixel.
+__global__ __launch_bounds__(256) void prepare_feature_kernel(const float* __restrict__ src, int cs, float* __restrict__ dst, int ldd,
+                                                              const dd_feature_params fp, int B, int H, int W, int tiles_x, int tiles_y) {
+  constexpr int TP = 16, HP = TP + 2;
+  __shared__ float s_std[3][HP][HP + 1];     // standardised value
+  __shared__ float s_var[3][HP][HP + 1];     // the variance source: raw (variance_before) or standardised
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * TP, x0 = tx * TP;
   const float* img = src + (long)b * H * W * cs;
+  for (int k = threadIdx.x; k < HP * HP; k += 256) {
+    const int py = k / HP, px = k - py * HP;
+    // mirror exactly like the per-pixel formula did: sym_index of the neighbour coordinate (coordinates past a ragged tile are clamped, unused)
+    const int gy = sym_index(min(y0 - 1 + py, H), H), gx = sym_index(min(x0 - 1 + px, W), W);
+    for (int c = 0; c < cs; ++c) {
+      const float v = img[((long)gy * W + gx) * cs + c];
+      const float sv = standardize(v, fp);
+      s_std[c][py][px] = sv;
+      s_var[c][py][px] = fp.variance_before ? v : sv;
+    }
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  const int y = y0 + ly, x = x0 + lx;
+  if (y >= H || x >= W) return;
   float s[3];
-  for (int c = 0; c < cs; ++c) s[c] = standardize(img[((long)y * W + x) * cs + c], fp);
+  for (int c = 0; c < cs; ++c) s[c] = s_std[c][ly + 1][lx + 1];
+  const long i = ((long)b * H + y) * W + x;
   float* o = dst + i * ldd;
-  o[0] = s[0]; o[1] = cs == 3 ? s[1] : s[0]; o[2] = cs == 3 ? s[2] : s[0];
-  if (!fp.use_variance) return;
+  const bool one_store = ldd == 4 && (!fp.use_variance || fp.compress);      // the whole pixel record is one float4
+  float4 rec = make_float4(s[0], cs == 3 ? s[1] : s[0], cs == 3 ? s[2] : s[0], 0.f);
+  if (!one_store) { o[0] = rec.x; o[1] = rec.y; o[2] = rec.z; }
+  if (!fp.use_variance) {
+    if (one_store) *reinterpret_cast<float4*>(o) = rec;
+    return;
+  }
   float var_acc = 0.f;
   for (int c = 0; c < cs; ++c) {
     float sum = 0.f, sumsq = 0.f;
     int cnt = 0;
+#pragma unroll
     for (int a = -1; a <= 1; ++a)
+#pragma unroll
       for (int bb = -1; bb <= 1; ++bb) {
         if (fp.mode_neighbor && a != 0 && bb != 0) continue;
-        float v = img[((long)sym_index(y + a, H) * W + sym_index(x + bb, W)) * cs + c];
-        if (!fp.variance_before) v = standardize(v, fp);
+        const float v = s_var[c][ly + 1 + a][lx + 1 + bb];
         sum += v; sumsq += v * v; ++cnt;
       }
     const float mean = sum / cnt, meansq = sumsq / cnt;
@@ -268,42 +326,58 @@ __global__ void prepare_feature_kernel(const float* __restrict__ src, int cs, fl
     if (fp.relative) var = var / fmaxf(mean * mean, fp.epsilon);
     if (fp.compress) var_acc += var; else o[3 + c] = var;
   }
-  if (fp.compress) o[3] = var_acc / cs;
+  if (fp.compress) {
+    if (one_store) { rec.w = var_acc / cs; *reinterpret_cast<float4*>(o) = rec; }
+    else o[3] = var_acc / cs;
+  }
 }
 extern "C" int dd_prepare_feature(const float* src, int cs, float* dst, int ldd, const dd_feature_params* fp, int B, int H, int W, dd_stream stream) {
   DD_REQUIRE(src && dst && fp && (cs == 1 || cs == 3), "dd_prepare_feature: cs must be 1 or 3");
   const int nv = fp->use_variance ? (fp->compress ? 1 : cs) : 0;
   DD_REQUIRE(ldd >= 3 + nv, "dd_prepare_feature: ldd=%d too small for %d channels", ldd, 3 + nv);
-  const long total = (long)B * H * W;
-  hipLaunchKernelGGL(prepare_feature_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), src, cs, dst, ldd, *fp, B, H, W);
+  const int tiles_x = dd_ceil_div(W, 16), tiles_y = dd_ceil_div(H, 16);
+  hipLaunchKernelGGL(prepare_feature_kernel, dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(256), 0, S(stream), src, cs, dst, ldd, *fp, B, H, W, tiles_x, tiles_y);
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
 
+// One thread = one pixel x 16 bytes of destination channels (8 bf16 / 4 f32): a wave writes 1 KiB of contiguous network input per
+// store (the first version wrote every channel of a pixel with its own 2-byte store).  The tuple's entry table is tiny and read through
+// the scalar cache; each destination channel takes its value from the one entry that covers it.
 template <typename T>
 __global__ void gather_input_kernel(const dd_gather_entry* __restrict__ table, int n_tuples, int n_entries, T* __restrict__ dst, int ld,
                                     int c_pad, int B, long hw) {
-  const long total = (long)n_tuples * B * hw;
+  constexpr int N = Elem<T>::PER16;
+  const int groups = c_pad / N;
+  const long total = (long)n_tuples * B * hw * groups;
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const long pix = i % hw;
-  const long tb = i / hw;
+  const int c0 = (int)(i % groups) * N;
+  const long p = i / groups;
+  const long pix = p % hw;
+  const long tb = p / hw;
   const int b = (int)(tb % B), t = (int)(tb / B);
-  T* o = dst + i * ld;
-  int used = 0;
+  float v[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) v[j] = 0.f;
   for (int e = 0; e < n_entries; ++e) {
     const dd_gather_entry en = table[t * n_entries + e];
-    if (en.nch <= 0) continue;
+    if (en.nch <= 0 || en.dst_ch >= c0 + N || en.dst_ch + en.nch <= c0) continue;
     const float* s = en.src + ((long)b * en.batch_stride_pixels + pix) * en.pixel_stride;
-    for (int c = 0; c < en.nch; ++c) o[en.dst_ch + c] = Elem<T>::from_f32(s[c]);
-    used = max(used, en.dst_ch + en.nch);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int k = c0 + j - en.dst_ch;
+      if (k >= 0 && k < en.nch) v[j] = s[k];
+    }
   }
-  for (int c = used; c < c_pad; ++c) o[c] = Elem<T>::from_f32(0.f);
+  vstore<T>(dst + p * ld + c0, v);
 }
 extern "C" int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
                                int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(table && dst && n_tuples > 0 && n_entries > 0 && c_pad <= ld, "dd_gather_input: bad arguments");
-  const long total = (long)n_tuples * B * H * W;
+  const int per16 = dtype == DD_F32 ? 4 : 8;
+  DD_REQUIRE(c_pad % per16 == 0 && ld % per16 == 0, "dd_gather_input: c_pad=%d and ld=%d must be multiples of %d", c_pad, ld, per16);
+  const long total = (long)n_tuples * B * H * W * (c_pad / per16);
   if (dtype == DD_F32) hipLaunchKernelGGL(gather_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (float*)dst, ld, c_pad, B, (long)H * W);
   else hipLaunchKernelGGL(gather_input_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (bf16_t*)dst, ld, c_pad, B, (long)H * W);
   DD_LAUNCH_CHECK();

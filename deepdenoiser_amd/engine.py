@@ -429,14 +429,14 @@ class Graph:
         lib, code = self.lib, self.code
 
         def run(stream):
-            L.check(lib.dd_maxpool_fwd(x.ptr, x.ld, y.ptr, y.ld, idx.data_ptr(), x.Cp, x.B, x.H, x.W, pool, stride, code, stream))
+            L.check(lib.dd_maxpool_fwd(x.ptr, x.ld, y.ptr, y.ld, idx.data_ptr(), x.Cp, x.B, x.H, x.W, pool, stride, 1 if x.relu else 0, code, stream))
         self.fwd(run, "maxpool")
 
         def backward():
             if not (y.grad_written and x.requires_grad):
                 return
             gy, gx = y.grad(), x.grad()
-            mask = x if x.relu else None
+            mask = None          # the ReLU-backward mask of x is folded into idx by the forward kernel (relu_mask)
             acc = 1 if x.grad_written else 0
 
             def runb(stream):

@@ -95,9 +95,11 @@ int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream);
 /* column sums: out[c] += sum_rows x[row*ld + c]  (bias gradients; embedding-row gradients) */
 int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream);
 
-/* ---- max pooling, TF SAME (UNet.py:42-44 3x3/s2; Tiramisu.py:55-57 2x2/s2); idx = window argmax (uint8) */
+/* ---- max pooling, TF SAME (UNet.py:42-44 3x3/s2; Tiramisu.py:55-57 2x2/s2); idx = window argmax (uint8).
+ * relu_mask != 0: x is a ReLU output whose backward mask (x > 0) is folded into idx (255 = the window maximum is not positive, no
+ * gradient), so dd_maxpool_bwd can be called with mask == NULL. */
 int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
-                   int pool, int stride, int dtype, dd_stream stream);
+                   int pool, int stride, int relu_mask, int dtype, dd_stream stream);
 /* dx (+)= scatter(dy) masked by (mask>0) if mask != NULL */
 int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, const void* mask, int ldmask,
                    int C, int B, int H, int W, int pool, int stride, int accumulate, int dtype, dd_stream stream);
