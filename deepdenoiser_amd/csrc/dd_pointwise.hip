@@ -385,7 +385,7 @@ extern "C" int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n
 }
 
 // ------------------------------------------------------------------------------------------------ kernel prediction
-template <typename T, int KS>
+template <typename T, int KS, bool VEC>
 __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
                                 float* __restrict__ out, int ldo, int B, int H, int W) {
   constexpr int K2 = KS * KS, P = (KS - 1) / 2;
@@ -396,10 +396,23 @@ __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const 
   const long r = i / W;
   const int y = (int)(r % H);
   const int b = (int)(r / H);
-  float w[K2];
+  constexpr int N = Elem<T>::PER16, K2P = (K2 + N - 1) / N * N;      // logits are read as 16-byte vectors (ldl >= K2P, checked by the host)
+  float w[K2P];
   float mx = -INFINITY;
+  if (VEC) {
 #pragma unroll
-  for (int t = 0; t < K2; ++t) { w[t] = ld1<T>(logits + i * ldl + t); mx = fmaxf(mx, w[t]); }
+    for (int v = 0; v < K2P / N; ++v) {
+      float t8[N];
+      vload<T>(logits + i * ldl + v * N, t8);
+#pragma unroll
+      for (int e = 0; e < N; ++e) w[v * N + e] = t8[e];
+    }
+  } else {     // COMBINED tuples: member j's logits start at channel j * K2, not 16-byte aligned
+#pragma unroll
+    for (int t = 0; t < K2; ++t) w[t] = ld1<T>(logits + i * ldl + t);
+  }
+#pragma unroll
+  for (int t = 0; t < K2; ++t) mx = fmaxf(mx, w[t]);
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < K2; ++t) { w[t] = __expf(w[t] - mx); sum += w[t]; }
@@ -421,7 +434,7 @@ __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const 
   o[0] = o0; o[1] = o1; o[2] = o2;
 }
 
-template <typename T, int KS>
+template <typename T, int KS, bool VEC>
 __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
                                 const float* __restrict__ dout, int lddo, T* __restrict__ dlogits, int lddl, int dl_pad,
                                 int B, int H, int W) {
@@ -433,10 +446,23 @@ __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const 
   const long r = i / W;
   const int y = (int)(r % H);
   const int b = (int)(r / H);
-  float w[K2], dw[K2];
+  constexpr int N = Elem<T>::PER16, K2P = (K2 + N - 1) / N * N;
+  float w[K2P], dw[K2];
   float mx = -INFINITY;
+  if (VEC) {
 #pragma unroll
-  for (int t = 0; t < K2; ++t) { w[t] = ld1<T>(logits + i * ldl + t); mx = fmaxf(mx, w[t]); }
+    for (int v = 0; v < K2P / N; ++v) {
+      float t8[N];
+      vload<T>(logits + i * ldl + v * N, t8);
+#pragma unroll
+      for (int e = 0; e < N; ++e) w[v * N + e] = t8[e];
+    }
+  } else {     // COMBINED tuples: member j's logits start at channel j * K2, not 16-byte aligned
+#pragma unroll
+    for (int t = 0; t < K2; ++t) w[t] = ld1<T>(logits + i * ldl + t);
+  }
+#pragma unroll
+  for (int t = 0; t < K2; ++t) mx = fmaxf(mx, w[t]);
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < K2; ++t) { w[t] = __expf(w[t] - mx); sum += w[t]; }
@@ -458,9 +484,25 @@ __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const 
     }
   }
   T* o = dlogits + i * lddl;
+  if (!VEC) {
 #pragma unroll
-  for (int t = 0; t < K2; ++t) o[t] = Elem<T>::from_f32(w[t] * (dw[t] - dot));
-  for (int t = K2; t < dl_pad; ++t) o[t] = Elem<T>::from_f32(0.f);
+    for (int t = 0; t < K2; ++t) o[t] = Elem<T>::from_f32(w[t] * (dw[t] - dot));
+    for (int t = K2; t < dl_pad; ++t) o[t] = Elem<T>::from_f32(0.f);
+    return;
+  }
+#pragma unroll
+  for (int v = 0; v < K2P / N; ++v) {            // 16-byte stores; channels K2..dl_pad-1 are zero (dl_pad is a multiple of N, host-checked)
+    float t8[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) t8[e] = v * N + e < K2 ? w[v * N + e] * (dw[v * N + e < K2 ? v * N + e : 0] - dot) : 0.f;
+    if (v * N < dl_pad) vstore<T>(o + v * N, t8);
+  }
+  for (int t = K2P; t < dl_pad; t += N) {
+    float z[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) z[e] = 0.f;
+    vstore<T>(o + t, z);
+  }
 }
 
 template <typename T>
@@ -468,16 +510,24 @@ static int kpcn_dispatch(bool fwd, const float* src, int ldsrc, const void* logi
                          void* out, int ldo, int pad, int B, int H, int W, int ks, hipStream_t s) {
   const long total = (long)B * H * W;
   const dim3 g(grid_for(total, 128)), blk(128);
+  // 16-byte vector path: the logits (and, backward, the logit gradients) of this call start 16-byte aligned and are padded to whole vectors
+  constexpr int n = Elem<T>::PER16;
+  const int k2p = (ks * ks + n - 1) / n * n;
+  bool vec = ((uintptr_t)logits % 16) == 0 && ldl % n == 0 && ldl >= k2p;
+  if (!fwd) vec = vec && ((uintptr_t)out % 16) == 0 && ldo % n == 0 && pad % n == 0 && pad >= k2p;
+#define KP_LAUNCH(K, V)                                                                                                        \
+    if (fwd) hipLaunchKernelGGL((kpcn_fwd_kernel<T, K, V>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, (float*)out, ldo, B, H, W); \
+    else hipLaunchKernelGGL((kpcn_bwd_kernel<T, K, V>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, dout, lddo, (T*)out, ldo, pad, B, H, W);
 #define KP_CASE(K)                                                                                                             \
   case K:                                                                                                                      \
-    if (fwd) hipLaunchKernelGGL((kpcn_fwd_kernel<T, K>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, (float*)out, ldo, B, H, W); \
-    else hipLaunchKernelGGL((kpcn_bwd_kernel<T, K>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, dout, lddo, (T*)out, ldo, pad, B, H, W); \
+    if (vec) { KP_LAUNCH(K, true) } else { KP_LAUNCH(K, false) }                                                               \
     break;
   switch (ks) {
     KP_CASE(3) KP_CASE(5) KP_CASE(7)
     default: dd_set_error("kernel prediction: kernel_size %d unsupported (3, 5, 7)", ks); return DD_ERR_INVALID;
   }
 #undef KP_CASE
+#undef KP_LAUNCH
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
