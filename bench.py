@@ -146,11 +146,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if os.environ.get("DD_FORCE_DEVICE"):                  # test hook: several ranks on one GPU (with DD_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["DD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from deepdenoiser_amd import configs
     from deepdenoiser_amd.architecture import Architecture
