@@ -43,6 +43,22 @@ def synthetic_inputs(arch, B, H, W, device, seed):
     return feats, labels
 
 
+def measured_traffic(B, dtype):
+    """HBM bytes per conv_igemm launch from the committed PMC measurement of this configuration (profiles/*_hbm_traffic.json: FETCH_SIZE /
+    WRITE_SIZE passes of rocprofv3, collected and corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be collected from inside the
+    timed run, so the figure is reported only when a measurement of the same batch size and dtype exists; otherwise null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            m = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if m.get("tiles_per_gpu_per_step") == B and m.get("dtype") == dtype and "conv_igemm" in m:
+            c = m["conv_igemm"]
+            return {"bytes_per_launch": 1e6 * (c["fetch_MB_per_launch"] + c["write_MB_per_launch"]), "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def conv_flops(prog):
     """Algorithmic FLOPs of the MFMA conv launches (forward + data-gradient) of one step, from the logical layer shapes."""
     total = 0.0
@@ -209,8 +225,15 @@ def main():
         n, ms, flops = times[fam]
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        # algorithmic HBM bytes of the same launches: every input and output element once, plus the output-shaped operands some launches
+        # read (the ReLU mask of a dgrad, a residual, the gradient a launch accumulates into)
+        esz = 2 if args.dtype == "bf16" else 4
+        alg_bytes = sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r["extra_reads"])) * esz for r in trainer.program.g.conv_records)
+        tr = measured_traffic(B, args.dtype)
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (fwd+dgrad implicit GEMM)" % args.dtype, "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches_per_step": n, "avg_launch_us": 1e3 * ms / n,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": tr["bytes_per_launch"] if tr else None,
+                "traffic_source": tr["source"] if tr else None, "algorithmic_bytes_per_launch": alg_bytes / n,
+                "launches_per_step": n, "avg_launch_us": 1e3 * ms / n,
                 "algorithmic_gflop_per_step": flops / 1e9,
                 "other_kernels_ms_per_step": {k: round(v[1], 3) for k, v in times.items() if k != fam}}
     if rank == 0:

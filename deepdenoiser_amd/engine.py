@@ -253,7 +253,8 @@ class Graph:
     # ------------------------------------------------------------------ conv launches
     def _conv_call(self, x, wp, taps, n_pad, k_pad, bias, nbias, res, mask, y, B, H, W, flags, nk=None):
         if nk is not None:   # algorithmic FLOPs of this launch from the LOGICAL layer shape (roofline accounting, bench.py)
-            self.conv_records.append({"flops": 2.0 * B * H * W * taps * nk[0] * nk[1], "B": B, "H": H, "W": W, "taps": taps, "n": nk[0], "k": nk[1]})
+            self.conv_records.append({"flops": 2.0 * B * H * W * taps * nk[0] * nk[1], "B": B, "H": H, "W": W, "taps": taps, "n": nk[0], "k": nk[1],
+                                      "extra_reads": (1 if mask is not None else 0) + (1 if res is not None else 0) + (1 if flags & L.ACCUM else 0)})
         a = L.ConvArgs()
         a.x, a.ldx, a.cin = x.ptr, x.ld, x.Cp
         a.wp, a.k_pad, a.n_pad = wp.data_ptr(), k_pad, n_pad
