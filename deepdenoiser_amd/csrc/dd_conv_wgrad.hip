@@ -386,30 +386,44 @@ __device__ __forceinline__ void dma_1k(const void* gptr, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory");
 }
 
-constexpr int WG_PCH = 41;                        // 1 KiB chunks of the 18x18 x tile (324 pixels -> 40.5)
-constexpr int WG_P_BYTES = WG_PCH * 1024, WG_Q_BYTES = DD_TILE * DD_TILE * DD_LDS_ROW, WG_BUF = WG_P_BYTES + WG_Q_BYTES;
+// LDS image of one tile: the x tile (18x18 haloed for 3x3 layers: 324 pixels -> 41 chunks of 1 KiB; 16x16 for 1x1 layers: 32 chunks)
+// followed by the 16x16 dy tile (32 chunks); two such images (double buffer).
+template <bool HALO> struct WgLds {
+  static constexpr int PW = HALO ? DD_TILE + 2 : DD_TILE;
+  static constexpr int PCH = HALO ? 41 : 32;
+  static constexpr int P_BYTES = PCH * 1024, Q_BYTES = DD_TILE * DD_TILE * DD_LDS_ROW, BUF = P_BYTES + Q_BYTES;
+};
 
-// 8 waves, 2 per SIMD: wave w computes input-channel tile (w & 3) x output-channel tiles {2*(w>>2), 2*(w>>2)+1} x 9 taps (72
-// accumulator registers).  With ONE wave per SIMD every s_waitcnt and every address instruction delays the next MFMA (in-order issue):
-// the 72-step loop measured 9.8k cycles per tile against 4.6k of pure MFMA time even without the DMA pieces; two waves per SIMD fill
-// each other's gaps.
-template <bool IN_RELU>
+// 8 waves, 2 per SIMD (with ONE wave per SIMD every s_waitcnt and every address instruction delays the next MFMA -- in-order issue:
+// the same loop measured 9.8k cycles per tile against 4.6k of pure MFMA time; two waves per SIMD fill each other's gaps).
+//   MODE 0 (3x3):         wave = input-channel tile (w & 3) x output-channel half (w >> 2), all 9 taps: 72 accumulator registers.
+//   MODE 1 (3x3, <= 32 x 32 channels, e.g. the 24-channel compose net): only 2 x 1 channel-tile pairs exist, so the waves split the
+//                         TAPS instead: wave = input tile (w & 1) x tap group (w >> 1) = taps {0,1,2} {3,4} {5,6} {7,8}.  Every gradient
+//                         element still has exactly one owner (no extra atomics), each wave runs 24 steps per tile instead of 72.
+//   MODE 2 (1x1):         as MODE 0 with one tap and no halo; the loop is 8 steps, fully unrolled.
+template <bool IN_RELU, int MODE>
 __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using T = bf16_t;
-  constexpr int TAPS = 9, KC = 64, NPW = 2, PW = DD_TILE + 2;
-  constexpr int QPC = 4, PPC = 6;                  // DMA pieces per wave and tile: 32 dy chunks / 8 waves, ceil(41 x chunks / 8)
+  constexpr bool HALO = MODE != 2;
+  using LD = WgLds<HALO>;
+  constexpr int KC = 64, NPW = 2, PW = LD::PW, WG_BUF = LD::BUF, WG_P_BYTES = LD::P_BYTES;
+  constexpr int TW = MODE == 0 ? 9 : MODE == 1 ? 3 : 1;      // taps per k-step in this wave's loop
+  constexpr int QPC = 4, PPC = HALO ? 6 : 4, NP = QPC + PPC; // DMA pieces per wave and tile
+  constexpr int HSTEP = 2 * TW, NSTEP = 4 * HSTEP;           // steps per loop iteration (2 k-steps) / per tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // (channel-slice pair, split index): slices with fewer valid channel tiles get fewer workgroups (they finish their tiles faster)
   int combo = 0;
   while (combo + 1 < a.ncombo && (int)blockIdx.x >= a.cstart[combo + 1]) ++combo;
   const int ks = blockIdx.x - a.cstart[combo], ksplit = a.cstart[combo + 1] - a.cstart[combo];
   const int ms = combo / a.nslices, ns = combo - ms * a.nslices;
-  const int mi = wave & 3, nj = (wave >> 2) * NPW;
-  const bool active = mi * 16 < a.m - ms * KC && nj * 16 < a.n - ns * KC;   // this wave's channel tiles exist (24-channel layers: 2 of 8 waves)
+  const int mi = MODE == 1 ? wave & 1 : wave & 3, nj = MODE == 1 ? 0 : (wave >> 2) * NPW;
+  const int tbase = MODE == 1 ? ((wave >> 1) == 0 ? 0 : 1 + 2 * (wave >> 1)) : 0;      // MODE 1: first tap of this wave's group
+  const int ntw = MODE == 1 ? ((wave >> 1) == 0 ? 3 : 2) : TW;                         //         and how many it owns
+  const bool active = mi * 16 < a.m - ms * KC && nj * 16 < a.n - ns * KC;   // this wave's channel tiles exist
   const T* __restrict__ P = reinterpret_cast<const T*>(a.p);
   const T* __restrict__ Q = reinterpret_cast<const T*>(a.q);
-  const bool bias_q = a.bias_mode == 1 && ms == 0;
+  const bool bias_wave = a.bias_mode == 1 && ms == 0 && (MODE == 1 ? wave == 0 : mi == 0);   // sums the dy fragments it reads anyway
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #ifdef DD_PROFILE_PHASES
   const unsigned long long k_t0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
@@ -423,19 +437,26 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   const int per_img = a.tiles_y * a.tiles_x;
   const int total_tiles = a.B * per_img;
   // per-lane, tile-invariant part of the DMA source addresses (byte offsets from the tile's origin pixel)
-  int q_off[2];                 // dy chunk c = wave*4 + k: tile row c >> 1, pixels (c & 1)*8 + r
+  int q_off[2];                 // 16x16 tiles: chunk c = wave*4 + k is tile row c >> 1, pixels (c & 1)*8 + r
 #pragma unroll
   for (int h = 0; h < 2; ++h) q_off[h] = ((h * 8 + r) * a.ldq + qch) * 2;
-  int p_off[PPC], p_yx[PPC];    // x chunk c = k*8 + wave: pixel c*8 + r of the 18x18 haloed tile
+  int p_off[PPC], p_yx[PPC];    // haloed x tile: chunk c = k*8 + wave is pixels c*8 + r of the 18x18 tile; 1x1: as the dy tile
 #pragma unroll
   for (int k = 0; k < PPC; ++k) {
-    const int pix = (k * 8 + wave) * 8 + r;
-    const int py = (pix * 3641) >> 16, px = pix - py * PW;      // pix / 18 for pix < 400
-    p_off[k] = ((py * a.win + px) * a.ldp + pch) * 2;
-    p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (255 << 8);     // dummy pixels of the last chunk: always out of range
+    if (HALO) {
+      const int pix = (k * 8 + wave) * 8 + r;
+      const int py = (pix * 3641) >> 16, px = pix - py * PW;      // pix / 18 for pix < 400
+      p_off[k] = ((py * a.win + px) * a.ldp + pch) * 2;
+      p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (255 << 8);     // dummy pixels of the last chunk: always out of range
+    } else {
+      const int c = wave * PPC + k, py = c >> 1, px = (c & 1) * 8 + r;
+      p_off[k] = ((py * a.win + px) * a.ldp + pch) * 2;
+      p_yx[k] = (py << 8) | px;
+    }
   }
 
   struct Origin { const char* q; const char* p; int y0, x0; bool live; };
+  constexpr int HO = HALO ? 1 : 0;
   auto origin = [&](int tile) {
     Origin o;
     o.live = tile < total_tiles;
@@ -444,7 +465,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
     const int ty = rem / a.tiles_x;
     o.y0 = ty * DD_TILE; o.x0 = (rem - ty * a.tiles_x) * DD_TILE;
     o.q = reinterpret_cast<const char*>(Q + ((long)b * a.H * a.W + (long)o.y0 * a.W + o.x0) * a.ldq);
-    o.p = reinterpret_cast<const char*>(P + ((long)b * a.hin * a.win + (long)(o.y0 - 1) * a.win + (o.x0 - 1)) * a.ldp);
+    o.p = reinterpret_cast<const char*>(P + ((long)b * a.hin * a.win + (long)(o.y0 - HO) * a.win + (o.x0 - HO)) * a.ldp);
     return o;
   };
   // DMA piece k of the tile at `o` into buffer `sel`: k < QPC -> dy chunk, else x chunk
@@ -455,26 +476,26 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
       const bool ok = o.live && q_ok && o.y0 + row < a.H && o.x0 + h * 8 + r < a.W;
       dma_1k(ok ? o.q + (long)row * a.W * a.ldq * 2 + q_off[h] : zero, buf + WG_P_BYTES + c * 1024);
     } else {
-      const int kk = k - QPC, c = kk * 8 + wave;
-      if (c < WG_PCH) {      // wave-uniform
-        const int gy = o.y0 - 1 + (p_yx[kk] >> 8), gx = o.x0 - 1 + (p_yx[kk] & 255);
+      const int kk = k - QPC, c = HALO ? kk * 8 + wave : wave * PPC + kk;
+      if (c < LD::PCH) {      // wave-uniform
+        const int gy = o.y0 - HO + (p_yx[kk] >> 8), gx = o.x0 - HO + (p_yx[kk] & 255);
         const bool ok = o.live && p_ok && (unsigned)gy < (unsigned)a.hin && (unsigned)gx < (unsigned)a.win;
         dma_1k(ok ? o.p + p_off[kk] : zero, buf + c * 1024);
       }
     }
   };
 
-  f32x4_t acc[TAPS][NPW];
+  f32x4_t acc[TW][NPW];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < TW; ++t)
 #pragma unroll
     for (int j = 0; j < NPW; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum[NPW] = {0.f, 0.f};     // dy column sums of channels (nj + jj)*16 + lane&15 over this lane's pixels (the mi == 0 waves)
+  float bsum[NPW] = {0.f, 0.f};     // dy column sums of channels (nj + jj)*16 + lane&15 over this lane's pixels (bias_wave only)
 
   {
     const Origin o0 = origin(ks);
 #pragma unroll
-    for (int k = 0; k < QPC + PPC; ++k) piece(k, o0, 0);
+    for (int k = 0; k < NP; ++k) piece(k, o0, 0);
   }
   int sel = 0;
   for (int tile = ks; tile < total_tiles; tile += ksplit, sel ^= 1) {
@@ -485,53 +506,74 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
     const Origin on = origin(tile + ksplit);
     if (!active) {      // nothing to multiply: keep feeding the pipeline
 #pragma unroll
-      for (int k = 0; k < QPC + PPC; ++k) piece(k, on, sel ^ 1);
+      for (int k = 0; k < NP; ++k) piece(k, on, sel ^ 1);
       continue;
     }
     const char* ptile = smem + sel * WG_BUF;
     const char* qtile = ptile + WG_P_BYTES;
-    // 72 steps = 4 runtime iterations x (2 k-steps x 9 taps, unrolled).  Four tile rows further down the swizzle key repeats
-    // ((y*18 + x) & 7 is periodic in y with period 4), so the fragment addresses of iteration kp are those of iteration 0 plus
-    // kp * 4 rows: a few dozen address registers instead of one per step.
-    constexpr int HSTEP = 2 * TAPS, PADV = 4 * PW * DD_LDS_ROW, QADV = 4 * DD_TILE * DD_LDS_ROW;
+    // 4 loop iterations x (2 k-steps x TW taps, unrolled).  Four tile rows further down the swizzle key repeats ((y*18 + x) & 7 and
+    // (y*16 + x) & 7 are periodic in y with period 4 / 1), so the fragment addresses of iteration kp are those of iteration 0 plus kp * 4
+    // rows: a few dozen address registers instead of one per step.  (1x1: 8 steps in all, fully unrolled.)
+    constexpr int PADV = 4 * PW * DD_LDS_ROW, QADV = 4 * DD_TILE * DD_LDS_ROW;
     uint4 bq[2][NPW], ap[3];
     auto p_frag = [&](const char* pt, int hs) {      // hs = step within the iteration (may run 1-2 steps into the next one)
-      const int k2 = hs / TAPS, t = hs - k2 * TAPS;
-      uint4 v = frag_tr_bf16(pt, 2 * k2 + t / 3, PW, t % 3, mi, lane);
+      const int k2 = hs / TW, i = hs - k2 * TW;
+      const int t = MODE == 1 ? min(tbase + i, 8) : i;
+      const int dy = HALO ? (t * 11) >> 5 : 0, dx = HALO ? t - 3 * dy : 0;      // t / 3, t % 3 for t < 9
+      uint4 v = frag_tr_bf16(pt, 2 * k2 + dy, PW, dx, mi, lane);
       if (IN_RELU) v = relu16<T>(v);
       return v;
+    };
+    auto body = [&](int kp, int hs, const char* pt, const char* qt) {
+      const int k2 = hs / TW, i = hs - k2 * TW;
+      const int g = MODE == 2 ? kp * HSTEP + hs : hs;               // ring position (a compile-time constant at every call)
+      ap[(g + 2) % 3] = p_frag(pt, hs + 2);                         // the last two of the tile read past it: never used
+      if (TW >= NPW) {
+        if (i < NPW) bq[(k2 + 1) & 1][i] = frag_tr_bf16(qt, 2 * (k2 + 1), DD_TILE, 0, nj + i, lane);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) bq[(k2 + 1) & 1][j] = frag_tr_bf16(qt, 2 * (k2 + 1), DD_TILE, 0, nj + j, lane);
+      }
+#ifndef DD_EXP_NO_PIECE
+      // the NP DMA pieces of the next tile, spread evenly over the NSTEP steps (indices are compile-time constants at every call: a
+      // runtime index would move p_off / p_yx to scratch)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (kp == c) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k)
+            if ((k * NSTEP) / NP == c * HSTEP + hs) piece(k, on, sel ^ 1);
+        }
+#endif
+      if (i == (MODE == 0 ? 4 : 0) && bias_wave) {      // bias gradient from the dy fragments in registers
+#pragma unroll
+        for (int jj = 0; jj < NPW; ++jj) {      // bq[k2 & 1][jj]: 8 pixels of channel lane&15 of n-tile nj + jj
+          float f[8];
+          unpack8(bq[k2 & 1][jj], f);
+          bsum[jj] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) acc[i][j] = mfma_bf16(ap[g % 3], bq[k2 & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     };
 #pragma unroll
     for (int j = 0; j < NPW; ++j) bq[0][j] = frag_tr_bf16(qtile, 0, DD_TILE, 0, nj + j, lane);
     ap[0] = p_frag(ptile, 0);
     ap[1] = p_frag(ptile, 1);
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int kp = 0; kp < 4; ++kp)
+#pragma unroll
+        for (int hs = 0; hs < HSTEP; ++hs) body(kp, hs, ptile + kp * PADV, qtile + kp * QADV);
+    } else {
 #pragma unroll 1
-    for (int kp = 0; kp < 4; ++kp) {
-      const char* pt = ptile + kp * PADV;
-      const char* qt = qtile + kp * QADV;
+      for (int kp = 0; kp < 4; ++kp) {
+        const char* pt = ptile + kp * PADV;
+        const char* qt = qtile + kp * QADV;
 #pragma unroll
-      for (int hs = 0; hs < HSTEP; ++hs) {
-        const int k2 = hs / TAPS, t = hs - k2 * TAPS;
-        ap[(hs + 2) % 3] = p_frag(pt, hs + 2);                     // the last two of the tile read past it: never used
-        if (t < NPW) bq[(k2 + 1) & 1][t] = frag_tr_bf16(qt, 2 * (k2 + 1), DD_TILE, 0, nj + t, lane);
-#ifndef DD_EXP_NO_PIECE
-        if (hs % 6 == 2) {                                         // 3 pieces per iteration: 12 slots for the 10 pieces of the next tile
-          const int k = kp * 3 + hs / 6;
-          if (k < QPC + PPC) piece(k, on, sel ^ 1);
-        }
-#endif
-        if (t == 4 && bias_q && mi == 0) {       // bias gradient: the first input-channel wave of each n-half sums its dy fragments
-#pragma unroll
-          for (int jj = 0; jj < NPW; ++jj) {      // bq[k2 & 1][jj]: 8 pixels of channel lane&15 of n-tile nj + jj
-            float f[8];
-            unpack8(bq[k2 & 1][jj], f);
-            bsum[jj] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[hs % 3], bq[k2 & 1][j], acc[t][j]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int hs = 0; hs < HSTEP; ++hs) body(kp, hs, pt, qt);
       }
     }
     WPHASE_T(w3);
@@ -541,7 +583,9 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   WPHASE_T(e0);
   const int li = lane & 15, q4 = (lane >> 4) * 4;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int i = 0; i < TW; ++i) {
+    if (MODE == 1 && i >= ntw) continue;       // the padding step of a 2-tap group
+    const int t = tbase + i;
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       const int n = ns * KC + (nj + j) * 16 + li;
@@ -549,9 +593,10 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = ms * KC + mi * 16 + q4 + e;
-        if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e]);
+        if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[i][j][e]);
       }
     }
+  }
   if (a.bias_mode == 1) {
 #pragma unroll
     for (int jj = 0; jj < NPW; ++jj) {
@@ -559,7 +604,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
       b += __shfl_xor(b, 16);
       b += __shfl_xor(b, 32);
       const int c = ns * KC + (nj + jj) * 16 + li;
-      if (bias_q && mi == 0 && lane < 16 && c < a.n) atomicAdd(a.bias_out + c, b);
+      if (bias_wave && lane < 16 && c < a.n) atomicAdd(a.bias_out + c, b);
     }
   }
   WPHASE_T(e1);
@@ -567,6 +612,17 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 #ifdef DD_PROFILE_PHASES
   if (blockIdx.x == 0 && tid == 0) { dd_wphase_cycles[14] += __builtin_readcyclecounter() - k_t0; dd_wphase_cycles[15] += wall_clock64() - k_w0; }
 #endif
+}
+
+template <bool IN_RELU, int MODE>
+static void launch_dma_mode(const WgradP& p, long blocks, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)WgLds<MODE != 2>::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<IN_RELU, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_dma_kernel<IN_RELU, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
 }
 
 static int launch_dma(WgradP& p, hipStream_t stream) {
@@ -591,16 +647,12 @@ static int launch_dma(WgradP& p, hipStream_t stream) {
     if (k > total_tiles) k = total_tiles;
     p.cstart[c + 1] = p.cstart[c] + (int)k;
   }
-  const size_t lds = 2 * (size_t)WG_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   const long blocks = p.cstart[p.ncombo];
-  if (p.flags & DD_IN_RELU) hipLaunchKernelGGL((wgrad_dma_kernel<true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
-  else hipLaunchKernelGGL((wgrad_dma_kernel<false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  const bool relu = (p.flags & DD_IN_RELU) != 0;
+  const int mode = p.taps == 1 ? 2 : (p.m <= 32 && p.n <= 32) ? 1 : 0;
+  if (mode == 2) { if (relu) launch_dma_mode<true, 2>(p, blocks, stream); else launch_dma_mode<false, 2>(p, blocks, stream); }
+  else if (mode == 1) { if (relu) launch_dma_mode<true, 1>(p, blocks, stream); else launch_dma_mode<false, 1>(p, blocks, stream); }
+  else { if (relu) launch_dma_mode<true, 0>(p, blocks, stream); else launch_dma_mode<false, 0>(p, blocks, stream); }
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -628,7 +680,7 @@ static bool dma_enabled() {
 
 template <typename T>
 int dispatch(const WgradP& p, hipStream_t stream) {
-  if (sizeof(T) == 2 && p.taps == 9 && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && dma_enabled()) { WgradP q = p; return launch_dma(q, stream); }
+  if (sizeof(T) == 2 && (p.taps == 9 || p.taps == 1) && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && dma_enabled()) { WgradP q = p; return launch_dma(q, stream); }
   switch (p.taps) {
     case 9: return launch<T, 9>(p, stream);
     case 4: return launch<T, 4>(p, stream);
