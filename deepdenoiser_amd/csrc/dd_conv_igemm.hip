@@ -141,15 +141,20 @@ __device__ __forceinline__ void patch_load(uint4 (&reg)[PatchDim<HALO>::ITERS], 
     const int sy = 2, ay = tap >> 1, ax = tap & 1;
     const T* base = X + (long)tc.b * p.hin * p.win * p.ldx + ch0;
     const int ylo = HALO ? -1 : 0, yhi = p.H + (HALO ? 1 : 0), xhi = p.W + (HALO ? 1 : 0);
+    const T* ptr[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int yx = pl.yx[it];
       const int ly = oy + (yx >> 8), lx = ox + (yx & 255);
       const int gy = ly * sy + ay, gx = lx * sy + ax;
       const bool ok = vec_ok(it) && ly >= ylo && lx >= ylo && ly < yhi && lx < xhi && gy >= 0 && gx >= 0 && gy < p.hin && gx < p.win;
-      const T* ptr = ok ? base + ((long)gy * p.win + gx) * p.ldx + pl.slot * PER16 : zero;
-      if (it < pl.n_it) reg[it] = *reinterpret_cast<const uint4*>(ptr);
+      ptr[it] = ok ? base + ((long)gy * p.win + gx) * p.ldx + pl.slot * PER16 : zero;
     }
+    __builtin_amdgcn_sched_barrier(0);      // as on edge tiles: all addresses first, then the loads back to back
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+      if (it < pl.n_it) reg[it] = *reinterpret_cast<const uint4*>(ptr[it]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
