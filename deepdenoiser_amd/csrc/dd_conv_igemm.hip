@@ -617,9 +617,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
             uint2 pk;
             pk.x = pack_bf16x2(a[0], a[1]);
             pk.y = pack_bf16x2(a[2], a[3]);
-            // pixels li and li + 8 share their slot swizzle: they take opposite 8-byte halves of the slot, or every ds_write_b64 would be a
-            // 2-way bank conflict (the drain swaps the halves back for pixels with bit 3 set)
-            *reinterpret_cast<uint2*>(stage + lds_off(r * 16 + li, j * 2 + (q >> 1)) + (((q & 1) ^ (li >> 3)) << 3)) = pk;
+            *reinterpret_cast<uint2*>(stage + lds_off(r * 16 + li, j * 2 + (q >> 1)) + (q & 1) * 8) = pk;
           }
       }
       PHASE_T(m3);
@@ -680,7 +678,6 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
           okv[k] = lane_ok && (interior || (tc.y0 + w4 * 4 + (pixl >> 4) < p.H && tc.x0 + (pixl & 15) < p.W));
           pixv[k] = okv[k] ? tile_pix + abpix + e_pix[it] : tile_pix;
           pv[k] = *reinterpret_cast<const uint4*>(stage + e_lds[it]);
-          if (pixl & 8) pv[k] = uint4{pv[k].z, pv[k].w, pv[k].x, pv[k].y};      // undo the half swap of the stage writer
           if (M) mv[k] = *reinterpret_cast<const uint4*>(M + pixv[k] * p.ldmask + ch);
           if (R) rv[k] = *reinterpret_cast<const uint4*>(R + pixv[k] * p.ldres + ch);
           if (accum) av[k] = *reinterpret_cast<const uint4*>(Y + pixv[k] * p.ldy + ch);
