@@ -140,6 +140,35 @@ def inference_bench(args, device, rank, world):
                           "config": {"workload": "BASELINE config 5: full-frame 1920x1080 inference, 209 halo tiles (overlap 14), tiles per batch %d" % args.batch}}))
 
 
+def augment_bench(args, device, rank, world):
+    """Device data augmentation of one batch of cfg-2 tiles: every source pass + the target, one dd_augment launch each.
+    HBM-bound: each element is read once and written once (fp32)."""
+    from deepdenoiser_amd import configs
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.data_augmentation import DataAugmentation, DataAugmentationUsage
+    arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype=args.dtype, seed=2)
+    B, T = args.batch, args.tile
+    feats, labels = synthetic_inputs(arch, B, T, T, device, seed=3 + rank)
+    usage = DataAugmentationUsage(True, False, True, True)              # TrainingExample.json:17-23
+    draws = DataAugmentation.draw(B, generator=torch.Generator().manual_seed(1))
+    for _ in range(max(1, args.warmup)):
+        DataAugmentation.apply(feats, labels, draws, usage)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        DataAugmentation.apply(feats, labels, draws, usage)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = 2 * 4 * sum(v.numel() for v in list(feats.values()) + list(labels.values()))
+    if rank == 0:
+        gbs = nbytes * args.steps / dt / 1e9
+        print(json.dumps({"metric": "data augmentation tiles/s (rot90 + rgb permutation + normal rotation, all passes of a 128x128x32ch tile)",
+                          "value": world * B * args.steps / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "augmentation of %d tiles x %d tensors per step (incl. host-side launch overhead)" % (B, len(feats) + len(labels))},
+                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +179,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="train", choices=["train", "inference"],
+    ap.add_argument("--mode", default="train", choices=["train", "inference", "augment"],
                     help="inference: full-frame 1920x1080 halo-tiled prediction (BASELINE config 5), reported as MPix/s -- a secondary line, "
                          "the driver's contract is the default train mode")
     ap.add_argument("--host-inputs", action="store_true",
@@ -180,6 +209,8 @@ def main():
 
     if args.mode == "inference":
         return inference_bench(args, device, rank, world)
+    if args.mode == "augment":
+        return augment_bench(args, device, rank, world)
 
     aj, tj = configs.cfg2_unet_kpcn(), configs.bench_training()
     arch = Architecture(aj, device=device, dtype=args.dtype, seed=2)       # identical init on every rank

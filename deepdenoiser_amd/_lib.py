@@ -21,6 +21,7 @@ SYMBOLS = (
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
+    "dd_augment",
 )
 
 
@@ -70,6 +71,13 @@ class LossDesc(C.Structure):
                 ("n_image_combined", C.c_int), ("image_combined", C.c_int * MAX_COMBINED),
                 ("n_image_features", C.c_int), ("image_features", C.c_int * MAX_FEATURES),
                 ("image_weight", C.c_float), ("kind", C.c_int), ("epsilon", C.c_float)]
+
+
+class AugmentDraw(C.Structure):
+    _fields_ = [("flip", C.c_int), ("rotate", C.c_int), ("permute", C.c_int), ("normal_rotation", C.c_float * 9)]
+
+
+AUG_PLAIN, AUG_RGB, AUG_NORMAL, AUG_SCREEN_NORMAL = 0, 1, 2, 3
 
 
 class StitchEntry(C.Structure):
@@ -132,6 +140,7 @@ def load():
     lib.dd_convert_channels.argtypes = [vp, i, i, vp, i, i, i, i, l, vp]
     lib.dd_zero_stuff.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
     lib.dd_zero_unstuff.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
+    lib.dd_augment.argtypes = [vp, vp, i, i, i, i, vp, i, i, i, i, i, vp]
     _lib = lib
     return lib
 

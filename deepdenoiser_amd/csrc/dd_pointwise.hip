@@ -544,6 +544,72 @@ extern "C" int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int 
                          : kpcn_dispatch<bf16_t>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream));
 }
 
+// ------------------------------------------------------------------------------------------------ data augmentation
+// One thread = one OUTPUT pixel: the source pixel follows from inverting rot90(flip(.)), the channel transform depends on the pass kind.
+__global__ void augment_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int B, int H, int W,
+                               const dd_augment_draw* __restrict__ draws, int kind, int use_flip, int use_rotate, int use_permute,
+                               int use_normal_rotation) {
+  const long total = (long)B * H * W;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long r = i / W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  const dd_augment_draw d = draws[b];
+  const int k = use_rotate ? (d.rotate & 3) : 0;
+  const bool flip = use_flip && d.flip > 0;
+  // R = rot90(F, k) counter-clockwise (tf.image.rot90 / np.rot90): R[i][j] = F[j][N-1-i], F[N-1-i][N-1-j], F[N-1-j][i] for k = 1, 2, 3
+  int fy = y, fx = x;
+  if (k == 1) { fy = x; fx = W - 1 - y; }
+  else if (k == 2) { fy = H - 1 - y; fx = W - 1 - x; }
+  else if (k == 3) { fy = H - 1 - x; fx = y; }
+  if (flip) fx = W - 1 - fx;                      // F[y][x] = in[y][W-1-x]
+  const float* s = src + (((long)b * H + fy) * W + fx) * C;
+  float* o = dst + i * C;
+  if (C != 3) {
+    for (int c = 0; c < C; ++c) o[c] = s[c];
+    return;
+  }
+  float v0 = s[0], v1 = s[1], v2 = s[2];
+  if (kind == DD_AUG_SCREEN_NORMAL) {
+    if (flip) v0 = -v0;                             // DataAugmentation._flip_screen_space_normals
+    if (k == 1) { const float t = v0; v0 = -v1; v1 = t; }          // _rotate_90:  x -> -y, y -> x
+    else if (k == 2) { v0 = -v0; v1 = -v1; }                       // _rotate_180
+    else if (k == 3) { const float t = v1; v1 = -v0; v0 = t; }     // _rotate_270: x -> y, y -> -x
+  } else if (kind == DD_AUG_RGB && use_permute) {
+    const float a0 = v0, a1 = v1, a2 = v2;
+    switch (d.permute) {                            // DataAugmentation.permute_rgb: result[c] = input[permutation[c]]
+      case 1: v0 = a0; v1 = a2; v2 = a1; break;
+      case 2: v0 = a1; v1 = a0; v2 = a2; break;
+      case 3: v0 = a1; v1 = a2; v2 = a0; break;
+      case 4: v0 = a2; v1 = a0; v2 = a1; break;
+      case 5: v0 = a2; v1 = a1; v2 = a0; break;
+      default: break;
+    }
+  } else if (kind == DD_AUG_NORMAL && use_normal_rotation) {
+    const float* m = d.normal_rotation;             // tf.matmul(inputs [HW,3], rotation_matrix [3,3])
+    const float a0 = v0, a1 = v1, a2 = v2;
+    v0 = a0 * m[0] + a1 * m[3] + a2 * m[6];
+    v1 = a0 * m[1] + a1 * m[4] + a2 * m[7];
+    v2 = a0 * m[2] + a1 * m[5] + a2 * m[8];
+  }
+  o[0] = v0; o[1] = v1; o[2] = v2;
+}
+extern "C" int dd_augment(const float* src, float* dst, int C, int B, int H, int W, const dd_augment_draw* draws, int kind,
+                          int use_flip, int use_rotate, int use_permute, int use_normal_rotation, dd_stream stream) {
+  DD_REQUIRE(src && dst && draws && src != dst, "dd_augment: null or aliased pointers");
+  DD_REQUIRE(C == 1 || C == 3, "dd_augment: C=%d (1 or 3)", C);
+  DD_REQUIRE(kind >= DD_AUG_PLAIN && kind <= DD_AUG_SCREEN_NORMAL && (kind == DD_AUG_PLAIN || C == 3), "dd_augment: kind=%d needs 3 channels", kind);
+  DD_REQUIRE(!use_rotate || H == W, "dd_augment: rotate_90 needs square tiles (H=%d W=%d)", H, W);
+  DD_REQUIRE(!(kind == DD_AUG_NORMAL && use_flip), "dd_augment: flipping normals is not supported (DataAugmentation.py:22-23)");
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(augment_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), src, dst, C, B, H, W, draws, kind, use_flip, use_rotate,
+                     use_permute, use_normal_rotation);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ multiscale compose
 template <typename T>
 __global__ void compose_pack_kernel(const float* __restrict__ small, int lds, const float* __restrict__ fine, int ldf,

@@ -202,6 +202,17 @@ int dd_masked_add(void* dst, int lddst, const void* src, int ldsrc, const void* 
 /* dst[pix][0:nch] = convert(src[pix][0:nch]); dst[pix][nch:dst_pad] = 0   (dtype codes per tensor; fp32 <-> graph dtype) */
 int dd_convert_channels(const void* src, int src_dtype, int ldsrc, void* dst, int dst_dtype, int lddst, int nch, int dst_pad,
                         long npix, dd_stream stream);
+/* ---- data augmentation of one render pass of a batch of tiles (DataAugmentation.py:10-200 as applied by Training.py:794-821,
+ * FeatureTrainingAugmentation Training.py:551-604): dst[b] = rotate_normal(permute_rgb(rotate_90(flip_left_right(src[b])))) with
+ * per-tile draws.  src/dst: [B,H,W,C] float32, C = 1 or 3.  draws: B device records.  kind: DD_AUG_PLAIN (geometry only), DD_AUG_RGB
+ * (RenderPasses.is_rgb_color_render_pass: the channel permutation applies), DD_AUG_NORMAL (world-space normal: the 3x3 rotation applies;
+ * v_out = v_in * M, row vector times matrix), DD_AUG_SCREEN_NORMAL (flip negates x; rot90 k maps (x,y) -> (-y,x), (-x,-y), (y,-x)).
+ * use_* : the DataAugmentationUsage switches.  Rotation by an odd k needs H == W (tiles are square). */
+typedef struct { int flip; int rotate; int permute; float normal_rotation[9]; } dd_augment_draw;
+enum { DD_AUG_PLAIN = 0, DD_AUG_RGB = 1, DD_AUG_NORMAL = 2, DD_AUG_SCREEN_NORMAL = 3 };
+int dd_augment(const float* src, float* dst, int C, int B, int H, int W, const dd_augment_draw* draws, int kind,
+               int use_flip, int use_rotate, int use_permute, int use_normal_rotation, dd_stream stream);
+
 /* 3x3/s2 transpose conv (Tiramisu.py:62-64) = 3x3 SAME conv of the zero-stuffed input with the flipped kernel:
  * y[B,2H,2W,C] = 0 except y[2i+1,2j+1] = x[i,j]; and its adjoint dx[i,j] (+)= dy[2i+1,2j+1] * (mask>0). */
 int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, int B, int H, int W, int dtype, dd_stream stream);
