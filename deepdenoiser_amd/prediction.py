@@ -20,10 +20,11 @@ _SINGLES = ("Volume Direct", "Volume Indirect", "Environment", "Emission")
 
 
 class Predictor:
-    def __init__(self, architecture, tile_size=128, tile_overlap_size=14, tiles_per_batch=16):
+    def __init__(self, architecture, tile_size=128, tile_overlap_size=14, tiles_per_batch=16, use_graph=True):
         self.arch, self.tile_size, self.tile_overlap_size, self.tiles_per_batch = architecture, tile_size, tile_overlap_size, tiles_per_batch
         self.lib = L.load()
-        self._plans = {}
+        self.use_graph = use_graph
+        self._plans, self._graphs = {}, {}
 
     def prepare(self, H, W):
         """Build (and cache) the tile program for an HxW frame; the network parameters exist after this call, so weights are loaded
@@ -38,7 +39,8 @@ class Predictor:
         dev = self.arch.device
         plan = tile_plan(H, W, self.tile_size, self.tile_overlap_size)
         T = plan.tile
-        Bt = min(self.tiles_per_batch, plan.count)
+        n_batches = -(-plan.count // max(1, self.tiles_per_batch))
+        Bt = -(-plan.count // n_batches)          # balanced batches: 209 tiles at <= 64 per batch -> 4 x 53, not 3 x 64 + 17
         prog = self.arch.program(Bt, T, T)
         NF = prog.NF
         origins = plan.windows()                                                              # row-major (Prediction.py:380-382)
@@ -77,7 +79,7 @@ class Predictor:
         stream = prog.g.stream_ptr()
         for yy, xx, tdev, n in chunks:
             prog.set_inputs({k: frame[k][yy, xx] for k in names})        # one gather per pass: [Bt,T,T,C] halo tiles
-            prog.forward(pack=False)
+            self._forward(prog)
             tiles = prog.predictions[0]                                  # [NF*Bt, T, T, 3], feature-major
             L.check(lib.dd_stitch(tiles.ptr, T, 3, frames.data_ptr(), H, W, 3, 3, tdev.data_ptr(), n, stream))
         out = {}
@@ -86,6 +88,22 @@ class Predictor:
                 out[Naming.feature_prediction_name(f.name)] = frames[prog.head_index[f.name]][..., :f.number_of_channels]
         self._recombine(prog, frames, out, H * W, stream)
         return out
+
+    def _forward(self, prog):
+        """The tile program's forward launches, replayed from a hipGraph after one eager pass (the ~80 launches of a batch of tiles
+        cost more on the host than on the device once the kernels are fast)."""
+        if not self.use_graph:
+            prog.forward(pack=False)
+            return
+        gr = self._graphs.get(id(prog))
+        if gr is None:
+            prog.forward(pack=False)                 # eager once: binds every launch, warms the caches
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                prog.forward(pack=False)
+            self._graphs[id(prog)] = gr
+        gr.replay()
 
     def _recombine(self, prog, frames, out, npix, stream):
         idx = prog.head_index
