@@ -350,10 +350,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   }
   PatchPlan<HALO> plan;
   patch_plan<T, HALO>(plan, p, tid);
-#ifdef DD_STAGGER
-  // de-phase the workgroups: all CUs otherwise run load / MFMA / store phases in lockstep and HBM sees bursts
-  for (int i = 0; i < (int)(blockIdx.x % DD_STAGGER); ++i) __builtin_amdgcn_s_sleep(DD_STAGGER_SLEEP);
-#endif
   f32x4_t acc[NT][4];
   uint4 pre[PatchDim<HALO>::ITERS];
   uint4 wreg[(NT + 1) / 2];

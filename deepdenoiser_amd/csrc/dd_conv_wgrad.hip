@@ -340,11 +340,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = ms * KC + mi * 16 + q4 + e;
-#ifdef DD_EXP_WG_ATOMIC
-        if (m < a.m) __hip_atomic_fetch_add(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
         if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[t][j][e]);
-#endif
       }
     }
 
