@@ -65,12 +65,12 @@ class LossDesc(C.Structure):
                 ("pred", C.c_void_p * MAX_FEATURES), ("target", C.c_void_p * MAX_FEATURES),
                 ("dpred", C.c_void_p * MAX_FEATURES),
                 ("target_ld", C.c_int * MAX_FEATURES), ("pred_ld", C.c_int * MAX_FEATURES), ("nch", C.c_int * MAX_FEATURES),
-                ("weight", C.c_float * MAX_FEATURES),
+                ("weight", C.c_float * MAX_FEATURES), ("var_weight", C.c_float * MAX_FEATURES),
                 ("n_combined", C.c_int), ("comb", (C.c_int * 3) * MAX_COMBINED),
-                ("comb_weight", C.c_float * MAX_COMBINED),
+                ("comb_weight", C.c_float * MAX_COMBINED), ("comb_var_weight", C.c_float * MAX_COMBINED),
                 ("n_image_combined", C.c_int), ("image_combined", C.c_int * MAX_COMBINED),
                 ("n_image_features", C.c_int), ("image_features", C.c_int * MAX_FEATURES),
-                ("image_weight", C.c_float), ("kind", C.c_int), ("epsilon", C.c_float)]
+                ("image_weight", C.c_float), ("image_var_weight", C.c_float), ("kind", C.c_int), ("epsilon", C.c_float)]
 
 
 class AugmentDraw(C.Structure):

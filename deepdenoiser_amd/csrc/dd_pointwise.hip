@@ -819,54 +819,97 @@ __device__ __forceinline__ void loss_term(int kind, float eps, float p, float t,
   }
 }
 
-__global__ void loss_head_kernel(const dd_loss_desc d, long npix, float inv_count, float grad_scale, float* __restrict__ loss_out) {
+// Value of one loss "source" at a pixel: prediction and target, 3 channels (1-channel passes broadcast, tf.multiply broadcasting,
+// Training.py:422-426).
+struct Val3 { float p[3], t[3]; };
+__device__ __forceinline__ Val3 feature_value(const dd_loss_desc& d, int f, long i) {
+  Val3 v;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int cf = d.nch[f] == 1 ? 0 : c;
+    v.p[c] = d.pred[f][i * d.pred_ld[f] + cf];
+    v.t[c] = d.target[f][i * d.target_ld[f] + cf];
+  }
+  return v;
+}
+__device__ __forceinline__ Val3 combined_value(const dd_loss_desc& d, int k, long i) {      // color * (direct + indirect)
+  const Val3 c = feature_value(d, d.comb[k][0], i), dr = feature_value(d, d.comb[k][1], i), in = feature_value(d, d.comb[k][2], i);
+  Val3 v;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) { v.p[ch] = c.p[ch] * (dr.p[ch] + in.p[ch]); v.t[ch] = c.t[ch] * (dr.t[ch] + in.t[ch]); }
+  return v;
+}
+__device__ __forceinline__ Val3 image_value(const dd_loss_desc& d, long i) {                 // sum of the combined features and single passes
+  Val3 v = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  for (int j = 0; j < d.n_image_combined; ++j) {
+    const Val3 a = combined_value(d, d.image_combined[j], i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v.p[c] += a.p[c]; v.t[c] += a.t[c]; }
+  }
+  for (int j = 0; j < d.n_image_features; ++j) {
+    const Val3 a = feature_value(d, d.image_features[j], i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v.p[c] += a.p[c]; v.t[c] += a.t[c]; }
+  }
+  return v;
+}
+
+// Mean + variation terms of one source at pixel i: adds this pixel's share to `loss` and returns dLoss/dvalue(i) in g[0..nch).
+// A pair (i, neighbour) belongs to its left / upper pixel for the loss SUM; the gradient of every pair reaches both of its pixels.
+template <typename F>
+__device__ __forceinline__ void source_terms(F value, long i, int x, int y, int H, int W, int nch, float w_mean, float w_var, int kind,
+                                             float eps, float grad_scale, float& loss, float (&g)[3]) {
+  g[0] = g[1] = g[2] = 0.f;
+  if (w_mean == 0.f && w_var == 0.f) return;
+  const Val3 c = value(i);
+  if (w_mean != 0.f)
+    for (int ch = 0; ch < nch; ++ch) {
+      float l, dl;
+      loss_term(kind, eps, c.p[ch], c.t[ch], &l, &dl);
+      loss += w_mean * l;
+      g[ch] += w_mean * dl * grad_scale;
+    }
+  if (w_var == 0.f) return;
+  // (neighbour offset, exists, this pixel is the FIRST element of the pair)
+  const long off[4] = {1, -1, (long)W, -(long)W};
+  const bool ok[4] = {x + 1 < W, x > 0, y + 1 < H, y > 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!ok[k]) continue;
+    const Val3 n = value(i + off[k]);
+    const bool first = (k & 1) == 0;
+    for (int ch = 0; ch < nch; ++ch) {
+      // variation = second - first (Training.py:305-316: shift_left - shift_right = x[j+1] - x[j])
+      const float vp = first ? n.p[ch] - c.p[ch] : c.p[ch] - n.p[ch];
+      const float vt = first ? n.t[ch] - c.t[ch] : c.t[ch] - n.t[ch];
+      float l, dl;
+      loss_term(kind, eps, vp, vt, &l, &dl);
+      if (first) { loss += w_var * l; g[ch] -= w_var * dl * grad_scale; }
+      else g[ch] += w_var * dl * grad_scale;
+    }
+  }
+}
+
+__global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, float inv_count, float inv_count_var, float grad_scale,
+                                 float* __restrict__ loss_out) {
   __shared__ float red[256];
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   float loss = 0.f;
   if (i < npix) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
     for (int f = 0; f < d.n_features; ++f) {
-      const int nch = d.nch[f];
-      const float wgt = d.weight[f] * inv_count;
+      float g[3];
+      source_terms([&](long j) { return feature_value(d, f, j); }, i, x, y, H, W, d.nch[f], d.weight[f] * inv_count,
+                   d.var_weight[f] * inv_count_var, d.kind, d.epsilon, grad_scale, loss, g);
       float* dp = d.dpred[f] + i * 3;
-      for (int c = 0; c < 3; ++c) {
-        float g = 0.f;
-        if (c < nch && wgt != 0.f) {
-          float l, dl;
-          loss_term(d.kind, d.epsilon, d.pred[f][i * d.pred_ld[f] + c], d.target[f][i * d.target_ld[f] + c], &l, &dl);
-          loss += wgt * l;
-          g = wgt * dl * grad_scale;
-        }
-        dp[c] = g;
-      }
+      dp[0] = g[0]; dp[1] = g[1]; dp[2] = g[2];
     }
     if (d.n_combined > 0 || d.n_image_features > 0) {
       float dimg[3] = {0.f, 0.f, 0.f};
-      const bool use_image = d.image_weight != 0.f && (d.n_image_combined > 0 || d.n_image_features > 0);
+      const bool use_image = (d.image_weight != 0.f || d.image_var_weight != 0.f) && (d.n_image_combined > 0 || d.n_image_features > 0);
       if (use_image) {
-        float ip[3] = {0.f, 0.f, 0.f}, it[3] = {0.f, 0.f, 0.f};
-        for (int j = 0; j < d.n_image_combined; ++j) {
-          const int k = d.image_combined[j];
-          const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
-          for (int c = 0; c < 3; ++c) {   // 1-channel passes broadcast over the 3 channels (tf.multiply broadcasting, Training.py:422-426)
-            const int cc = d.nch[fc] == 1 ? 0 : c, cd = d.nch[fd] == 1 ? 0 : c, ci = d.nch[fi] == 1 ? 0 : c;
-            ip[c] += d.pred[fc][i * d.pred_ld[fc] + cc] * (d.pred[fd][i * d.pred_ld[fd] + cd] + d.pred[fi][i * d.pred_ld[fi] + ci]);
-            it[c] += d.target[fc][i * d.target_ld[fc] + cc] * (d.target[fd][i * d.target_ld[fd] + cd] + d.target[fi][i * d.target_ld[fi] + ci]);
-          }
-        }
-        for (int j = 0; j < d.n_image_features; ++j) {
-          const int f = d.image_features[j];
-          for (int c = 0; c < 3; ++c) {
-            const int cf = d.nch[f] == 1 ? 0 : c;
-            ip[c] += d.pred[f][i * d.pred_ld[f] + cf]; it[c] += d.target[f][i * d.target_ld[f] + cf];
-          }
-        }
-        const float wgt = d.image_weight * inv_count;
-        for (int c = 0; c < 3; ++c) {
-          float l, dl;
-          loss_term(d.kind, d.epsilon, ip[c], it[c], &l, &dl);
-          loss += wgt * l;
-          dimg[c] = wgt * dl * grad_scale;
-        }
+        source_terms([&](long j) { return image_value(d, j); }, i, x, y, H, W, 3, d.image_weight * inv_count, d.image_var_weight * inv_count_var,
+                     d.kind, d.epsilon, grad_scale, loss, dimg);
         for (int j = 0; j < d.n_image_features; ++j) {
           float* dp = d.dpred[d.image_features[j]] + i * 3;
           for (int c = 0; c < 3; ++c) dp[d.nch[d.image_features[j]] == 1 ? 0 : c] += dimg[c];
@@ -876,21 +919,16 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, float inv_coun
         const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
         bool in_image = false;
         for (int j = 0; j < d.n_image_combined; ++j) in_image |= (d.image_combined[j] == k);
-        const float wgt = d.comb_weight[k] * inv_count;
-        for (int c = 0; c < 3; ++c) {
-          const int cc = d.nch[fc] == 1 ? 0 : c, cd = d.nch[fd] == 1 ? 0 : c, ci = d.nch[fi] == 1 ? 0 : c;
-          const float pc = d.pred[fc][i * d.pred_ld[fc] + cc], pd = d.pred[fd][i * d.pred_ld[fd] + cd], pi = d.pred[fi][i * d.pred_ld[fi] + ci];
-          float g = (use_image && in_image) ? dimg[c] : 0.f;
-          if (wgt != 0.f) {
-            const float tc = d.target[fc][i * d.target_ld[fc] + cc], td = d.target[fd][i * d.target_ld[fd] + cd], ti = d.target[fi][i * d.target_ld[fi] + ci];
-            float l, dl;
-            loss_term(d.kind, d.epsilon, pc * (pd + pi), tc * (td + ti), &l, &dl);
-            loss += wgt * l;
-            g += wgt * dl * grad_scale;
-          }
-          d.dpred[fc][i * 3 + cc] += g * (pd + pi);
-          d.dpred[fd][i * 3 + cd] += g * pc;
-          d.dpred[fi][i * 3 + ci] += g * pc;
+        float g[3];
+        source_terms([&](long j) { return combined_value(d, k, j); }, i, x, y, H, W, 3, d.comb_weight[k] * inv_count,
+                     d.comb_var_weight[k] * inv_count_var, d.kind, d.epsilon, grad_scale, loss, g);
+        const Val3 c = feature_value(d, fc, i), dr = feature_value(d, fd, i), in = feature_value(d, fi, i);
+        for (int ch = 0; ch < 3; ++ch) {
+          const float gt = g[ch] + ((use_image && in_image) ? dimg[ch] : 0.f);
+          const int cc = d.nch[fc] == 1 ? 0 : ch, cd = d.nch[fd] == 1 ? 0 : ch, ci = d.nch[fi] == 1 ? 0 : ch;
+          d.dpred[fc][i * 3 + cc] += gt * (dr.p[ch] + in.p[ch]);
+          d.dpred[fd][i * 3 + cd] += gt * c.p[ch];
+          d.dpred[fi][i * 3 + ci] += gt * c.p[ch];
         }
       }
     }
@@ -908,7 +946,9 @@ extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float
              "dd_loss_head: bad descriptor");
   DD_REQUIRE(desc->kind >= 1 && desc->kind <= 5, "dd_loss_head: unknown loss kind %d", desc->kind);
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(loss_head_kernel, dim3(grid_for(npix)), dim3(256), 0, S(stream), *desc, npix, 1.f / (float)npix, grad_scale, loss_out);
+  const long npairs = (long)B * ((long)H * (W - 1) + (long)(H - 1) * W);
+  hipLaunchKernelGGL(loss_head_kernel, dim3(grid_for(npix)), dim3(256), 0, S(stream), *desc, npix, H, W, 1.f / (float)npix,
+                     npairs > 0 ? 1.f / (float)npairs : 0.f, grad_scale, loss_out);
   DD_LAUNCH_CHECK();
   return DD_OK;
 }

@@ -150,9 +150,11 @@ int dd_invert_std_fwd(const float* x, float* y, long n, int use_log1p, float mea
 /* dx = dy * d(invert)/dx evaluated at the standardized value x */
 int dd_invert_std_bwd(const float* x, const float* dy, float* dx, long n, int use_log1p, float mean, float std, dd_stream stream);
 
-/* ---- loss head (LossDifference.difference LossDifference.py:15-35; BaseFeatureTraining.mean/loss Training.py:126-129,
- * 210-243; Combined*FeatureTraining.initialize Training.py:420-437,475-495): per-pixel evaluation of every feature loss,
- * combined-feature loss (color*(direct+indirect)) and combined-image loss at one scale, fused with its own backward. */
+/* ---- loss head (LossDifference.difference LossDifference.py:15-35; BaseFeatureTraining.mean / variation_mean / loss
+ * Training.py:126-129,141-176,210-243,304-348; Combined*FeatureTraining.initialize Training.py:420-437,475-495): per-pixel evaluation of
+ * every feature loss, combined-feature loss (color*(direct+indirect)) and combined-image loss at one scale, fused with its own backward.
+ * Each of the three levels has a MEAN term (difference of the values) and a VARIATION term (difference of the horizontal and vertical
+ * finite differences x[.,j+1]-x[.,j], x[i+1,.]-x[i,.], averaged over all B*(H*(W-1)+(H-1)*W) pairs). */
 #define DD_MAX_FEATURES 32
 #define DD_MAX_COMBINED 8
 typedef struct {
@@ -163,13 +165,16 @@ typedef struct {
   int target_ld[DD_MAX_FEATURES];        /* pixel stride of target */
   int pred_ld[DD_MAX_FEATURES];          /* pixel stride of pred (3, or 4 when a source is echoed) */
   int nch[DD_MAX_FEATURES];
-  float weight[DD_MAX_FEATURES];         /* loss weight incl. scale factor; the 1/(B*H*W) mean is applied inside */
+  float weight[DD_MAX_FEATURES];         /* mean-term weight incl. scale factor; the 1/(B*H*W) mean is applied inside */
+  float var_weight[DD_MAX_FEATURES];     /* variation-term weight incl. scale factor */
   int n_combined;
   int comb[DD_MAX_COMBINED][3];          /* feature indices of color, direct, indirect */
   float comb_weight[DD_MAX_COMBINED];
+  float comb_var_weight[DD_MAX_COMBINED];
   int n_image_combined; int image_combined[DD_MAX_COMBINED];   /* indices into comb[] */
   int n_image_features; int image_features[DD_MAX_FEATURES];   /* indices into features */
   float image_weight;
+  float image_var_weight;
   int kind;                              /* 1 DIFFERENCE, 2 ABSOLUTE, 3 SMOOTH_ABSOLUTE, 4 SQUARED, 5 SMAPE */
   float epsilon;
 } dd_loss_desc;

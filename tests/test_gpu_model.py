@@ -237,3 +237,27 @@ def test_predictor_full_frame_matches_oracle_tiling():
     got = out[key].cpu().double()
     assert got.shape == want.shape
     assert rel_l2(got, want) < 1e-4, rel_l2(got, want)
+
+
+@pytest.mark.parametrize("loss_difference", ["SMAPE", "SMOOTH_ABSOLUTE"])
+def test_variation_loss_terms_parity_f32(loss_difference):
+    """Variation (finite-difference) loss terms at all three levels -- feature, combined feature, combined image
+    (Training.py:141-176, 210-243, 304-348) -- on top of the mean terms: loss value and every parameter gradient vs the oracle."""
+    _need_gpu()
+    aj = configs.architecture(filters=(16, 16), convs=1)                  # the literal example: 17 SINGLE tuples, all combined features + image
+    tj = configs.training(loss_difference=loss_difference, feature_variation=0.7, combined_variation=2.0, image_variation=3.0)
+    B, H, W = 2, 16, 32
+    oracle, arch, prog, feats, labels, dev, devl, _ = _pair(aj, "f32", B, H, W, tj)
+    loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    loss = prog.train_step(dev, devl)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), (float(loss), float(loss_o))
+    # the variation terms must actually contribute
+    tj0 = configs.training(loss_difference=loss_difference)
+    assert abs(float(OT.model_loss(oracle, aj, tj0, oracle.predict(feats), labels)) - float(loss_o)) > 1e-2 * abs(float(loss_o))
+    names = list(oracle.vs.vars.keys())
+    errs = []
+    for p, n, go in zip(arch.params.params, names, grads_o):
+        if float(go.abs().max()) > 0:
+            errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
+    print("variation-loss gradient rel-L2: median %.2e max %.2e" % (sorted(errs)[len(errs) // 2], max(errs)))
