@@ -100,7 +100,7 @@ class Predictor:
             prog.forward(pack=False)                 # eager once: binds every launch, warms the caches
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 prog.forward(pack=False)
             self._graphs[id(prog)] = gr
         gr.replay()

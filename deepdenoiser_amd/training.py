@@ -108,7 +108,9 @@ class Trainer:
         self._graphs = []
         for idx in range(len(self._segments)):
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            # thread_local: the RCCL watchdog thread of torch.distributed queries events while we capture; in the default
+            # "global" mode any such call from another thread invalidates the capture
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 self._run_segment_eager(idx)
             self._graphs.append(gr)
 
