@@ -21,7 +21,7 @@ SYMBOLS = (
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
-    "dd_augment",
+    "dd_augment", "dd_loss_mask_sums",
 )
 
 
@@ -66,11 +66,14 @@ class LossDesc(C.Structure):
                 ("dpred", C.c_void_p * MAX_FEATURES),
                 ("target_ld", C.c_int * MAX_FEATURES), ("pred_ld", C.c_int * MAX_FEATURES), ("nch", C.c_int * MAX_FEATURES),
                 ("weight", C.c_float * MAX_FEATURES), ("var_weight", C.c_float * MAX_FEATURES),
+                ("masked_weight", C.c_float * MAX_FEATURES), ("mask_feature", C.c_int * MAX_FEATURES),
                 ("n_combined", C.c_int), ("comb", (C.c_int * 3) * MAX_COMBINED),
                 ("comb_weight", C.c_float * MAX_COMBINED), ("comb_var_weight", C.c_float * MAX_COMBINED),
+                ("comb_masked_weight", C.c_float * MAX_COMBINED), ("comb_mask_feature", C.c_int * MAX_COMBINED),
                 ("n_image_combined", C.c_int), ("image_combined", C.c_int * MAX_COMBINED),
                 ("n_image_features", C.c_int), ("image_features", C.c_int * MAX_FEATURES),
-                ("image_weight", C.c_float), ("image_var_weight", C.c_float), ("kind", C.c_int), ("epsilon", C.c_float)]
+                ("image_weight", C.c_float), ("image_var_weight", C.c_float), ("kind", C.c_int), ("epsilon", C.c_float),
+                ("mask_sums", C.c_void_p)]
 
 
 class AugmentDraw(C.Structure):
@@ -141,6 +144,7 @@ def load():
     lib.dd_zero_stuff.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
     lib.dd_zero_unstuff.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
     lib.dd_augment.argtypes = [vp, vp, i, i, i, i, vp, i, i, i, i, i, vp]
+    lib.dd_loss_mask_sums.argtypes = [vp, i, i, i, vp, vp]
     _lib = lib
     return lib
 

@@ -95,7 +95,7 @@ def cfg3_tiramisu(filters=(16, 24, 32), convs=4):
 
 def training(learning_rate=1e-3, batch_size=8, loss_difference="SMAPE", multiscale_loss=True,
              feature_mean=1.0, combined_mean=5.0, image_mean=10.0, feature_variation=0.0, masked_mean=0.0,
-             combined_variation=0.0, image_variation=0.0):
+             combined_variation=0.0, image_variation=0.0, combined_masked_mean=0.0):
     """Content-equivalent of the reference's TrainingExample.json (defaults) with a few knobs."""
     stats = {"track_mean": True, "track_variation": False, "track_ms_ssim": False,
              "track_difference_histogram": False, "track_variation_difference_histogram": False}
@@ -117,7 +117,7 @@ def training(learning_rate=1e-3, batch_size=8, loss_difference="SMAPE", multisca
         "use_multiscale_loss": multiscale_loss,
         "use_multiscale_metrics": True,
         "combined_image_training_settings": {"loss_weights": w(image_mean, image_variation), "statistics": dict(stats if image_mean > 0 else stats_off)},
-        "combined_features_training_settings": {"loss_weights": w(combined_mean, combined_variation), "loss_weights_masked": w(0.0),
+        "combined_features_training_settings": {"loss_weights": w(combined_mean, combined_variation), "loss_weights_masked": w(combined_masked_mean),
                                                 "statistics": dict(stats if combined_mean > 0 else stats_off),
                                                 "statistics_masked": dict(stats_off)},
         "features_training_settings": {"loss_weights": w(feature_mean, feature_variation), "loss_weights_masked": w(masked_mean),

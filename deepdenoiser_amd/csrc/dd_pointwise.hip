@@ -890,6 +890,52 @@ __device__ __forceinline__ void source_terms(F value, long i, int x, int y, int 
   }
 }
 
+// Conv2dUtilities.non_zero_mask (Conv2dUtilities.py:69-74) of feature f's target at pixel i: sign(sum_c |t_c|)
+__device__ __forceinline__ float target_mask(const dd_loss_desc& d, int f, long i) {
+  float s = 0.f;
+  for (int c = 0; c < d.nch[f]; ++c) s += fabsf(d.target[f][i * d.target_ld[f] + c]);
+  return s > 0.f ? 1.f : 0.f;
+}
+// per-pixel weight of the masked mean: mask / mask_sum (0 when the batch has no masked pixel, Training.py:133-137)
+__device__ __forceinline__ float masked_pixel_weight(const dd_loss_desc& d, float w, int mask_f, int src, long i) {
+  if (w == 0.f || mask_f < 0 || d.mask_sums == nullptr) return 0.f;
+  const float msum = d.mask_sums[src];
+  return msum > 0.f ? w * target_mask(d, mask_f, i) / msum : 0.f;
+}
+
+__global__ void loss_mask_sums_kernel(const dd_loss_desc d, long npix, float* __restrict__ sums) {
+  __shared__ float red[256];
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  for (int src = 0; src < DD_MAX_FEATURES + DD_MAX_COMBINED; ++src) {       // block-uniform loop
+    const bool is_f = src < DD_MAX_FEATURES;
+    const int k = is_f ? src : src - DD_MAX_FEATURES;
+    if (is_f ? k >= d.n_features : k >= d.n_combined) continue;
+    const float w = is_f ? d.masked_weight[k] : d.comb_masked_weight[k];
+    const int mf = is_f ? d.mask_feature[k] : d.comb_mask_feature[k];
+    if (w == 0.f || mf < 0) continue;
+    red[threadIdx.x] = i < npix ? target_mask(d, mf, i) : 0.f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] != 0.f) atomicAdd(sums + src, red[0]);
+    __syncthreads();
+  }
+}
+extern "C" int dd_loss_mask_sums(const dd_loss_desc* desc, int B, int H, int W, float* mask_sums, dd_stream stream) {
+  DD_REQUIRE(desc && mask_sums && desc->n_features > 0 && desc->n_features <= DD_MAX_FEATURES && desc->n_combined <= DD_MAX_COMBINED,
+             "dd_loss_mask_sums: bad descriptor");
+  const long npix = (long)B * H * W;
+  if (hipMemsetAsync(mask_sums, 0, sizeof(float) * (DD_MAX_FEATURES + DD_MAX_COMBINED), S(stream)) != hipSuccess) {
+    dd_set_error("dd_loss_mask_sums: hipMemsetAsync failed");
+    return DD_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(loss_mask_sums_kernel, dim3(grid_for(npix)), dim3(256), 0, S(stream), *desc, npix, mask_sums);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 __global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, float inv_count, float inv_count_var, float grad_scale,
                                  float* __restrict__ loss_out) {
   __shared__ float red[256];
@@ -899,7 +945,8 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, 
     const int x = (int)(i % W), y = (int)((i / W) % H);
     for (int f = 0; f < d.n_features; ++f) {
       float g[3];
-      source_terms([&](long j) { return feature_value(d, f, j); }, i, x, y, H, W, d.nch[f], d.weight[f] * inv_count,
+      source_terms([&](long j) { return feature_value(d, f, j); }, i, x, y, H, W, d.nch[f],
+                   d.weight[f] * inv_count + masked_pixel_weight(d, d.masked_weight[f], d.mask_feature[f], f, i),
                    d.var_weight[f] * inv_count_var, d.kind, d.epsilon, grad_scale, loss, g);
       float* dp = d.dpred[f] + i * 3;
       dp[0] = g[0]; dp[1] = g[1]; dp[2] = g[2];
@@ -920,7 +967,8 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, 
         bool in_image = false;
         for (int j = 0; j < d.n_image_combined; ++j) in_image |= (d.image_combined[j] == k);
         float g[3];
-        source_terms([&](long j) { return combined_value(d, k, j); }, i, x, y, H, W, 3, d.comb_weight[k] * inv_count,
+        source_terms([&](long j) { return combined_value(d, k, j); }, i, x, y, H, W, 3,
+                     d.comb_weight[k] * inv_count + masked_pixel_weight(d, d.comb_masked_weight[k], d.comb_mask_feature[k], DD_MAX_FEATURES + k, i),
                      d.comb_var_weight[k] * inv_count_var, d.kind, d.epsilon, grad_scale, loss, g);
         const Val3 c = feature_value(d, fc, i), dr = feature_value(d, fd, i), in = feature_value(d, fi, i);
         for (int ch = 0; ch < 3; ++ch) {

@@ -167,17 +167,26 @@ typedef struct {
   int nch[DD_MAX_FEATURES];
   float weight[DD_MAX_FEATURES];         /* mean-term weight incl. scale factor; the 1/(B*H*W) mean is applied inside */
   float var_weight[DD_MAX_FEATURES];     /* variation-term weight incl. scale factor */
+  float masked_weight[DD_MAX_FEATURES];  /* masked-mean weight incl. scale factor (BaseFeatureTraining.masked_mean, Training.py:131-137) */
+  int mask_feature[DD_MAX_FEATURES];     /* feature whose TARGET defines the mask (Conv2dUtilities.non_zero_mask of the corresponding colour pass) */
   int n_combined;
   int comb[DD_MAX_COMBINED][3];          /* feature indices of color, direct, indirect */
   float comb_weight[DD_MAX_COMBINED];
   float comb_var_weight[DD_MAX_COMBINED];
+  float comb_masked_weight[DD_MAX_COMBINED];
+  int comb_mask_feature[DD_MAX_COMBINED];
   int n_image_combined; int image_combined[DD_MAX_COMBINED];   /* indices into comb[] */
   int n_image_features; int image_features[DD_MAX_FEATURES];   /* indices into features */
   float image_weight;
   float image_var_weight;
   int kind;                              /* 1 DIFFERENCE, 2 ABSOLUTE, 3 SMOOTH_ABSOLUTE, 4 SQUARED, 5 SMAPE */
   float epsilon;
+  const float* mask_sums;                /* device, [DD_MAX_FEATURES + DD_MAX_COMBINED]: sum of each source's mask over the batch (dd_loss_mask_sums);
+                                            may be NULL when no masked weight is set */
 } dd_loss_desc;
+/* mask_sums[src] = sum over [B,H,W] of sign(sum_c |target_c|) of the source's mask feature, for every source with a masked weight
+ * (features first, then combined at DD_MAX_FEATURES + k).  The masked mean divides by this BATCH-global count (Training.py:131-137). */
+int dd_loss_mask_sums(const dd_loss_desc* desc, int B, int H, int W, float* mask_sums, dd_stream stream);
 /* loss_out[0] += total weighted loss of this scale; dpred written. desc is a HOST struct (copied by value). */
 int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float* loss_out, float grad_scale, dd_stream stream);
 

@@ -261,3 +261,43 @@ def test_variation_loss_terms_parity_f32(loss_difference):
         if float(go.abs().max()) > 0:
             errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
     print("variation-loss gradient rel-L2: median %.2e max %.2e" % (sorted(errs)[len(errs) // 2], max(errs)))
+
+
+def test_masked_mean_loss_terms_parity_f32():
+    """Masked means (Training.py:131-137): the mask is the non-zero mask of the corresponding colour pass's TARGET and the mean divides
+    by the batch-global mask count.  Targets get black regions so that the masks are non-trivial; one colour target of one pass is
+    black everywhere except a few pixels."""
+    _need_gpu()
+    combined = {"Diffuse": {"Color": "Diffuse Color", "Direct": "Diffuse Direct", "Indirect": "Diffuse Indirect"},
+                "Glossy": {"Color": "Glossy Color", "Direct": "Glossy Direct", "Indirect": "Glossy Indirect"}}
+    aj = configs.architecture(filters=(16, 16), convs=1, combined=combined)
+    tj = configs.training(image_mean=0.0, masked_mean=0.8, combined_masked_mean=1.7)
+    tj["combined_image_training_settings"]["statistics"]["track_mean"] = False
+    B, H, W = 2, 16, 32
+    from deepdenoiser_amd.architecture import Architecture
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(oracle, B, H, W)
+    for k in labels:
+        labels[k] = labels[k].clone()
+        labels[k][:, 3:9, 5:20] = 0.0                      # a black region in every target
+    kc = Naming.target_feature_name("Glossy Color")
+    labels[kc][:] = 0.0
+    labels[kc][0, 1, 1:4] = 0.3                            # almost everything masked out for the Glossy passes
+    oracle.predict(feats)
+    arch = Architecture(aj, device="cuda", dtype="f32")
+    prog = arch.program(B, H, W, training_json=tj)
+    arch.params.load_list(list(oracle.vs.vars.values()))
+    dev = {k: v.cuda() for k, v in feats.items()}
+    devl = {k: v.cuda() for k, v in labels.items()}
+    loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    loss = prog.train_step(dev, devl)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), (float(loss), float(loss_o))
+    tj0 = configs.training(image_mean=0.0)
+    tj0["combined_image_training_settings"]["statistics"]["track_mean"] = False
+    assert abs(float(OT.model_loss(oracle, aj, tj0, oracle.predict(feats), labels)) - float(loss_o)) > 1e-2 * abs(float(loss_o))
+    errs = []
+    for p, n, go in zip(arch.params.params, list(oracle.vs.vars.keys()), grads_o):
+        if float(go.abs().max()) > 0:
+            errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
+    print("masked-loss gradient rel-L2: median %.2e max %.2e" % (sorted(errs)[len(errs) // 2], max(errs)))

@@ -1,5 +1,5 @@
-"""Per-launch breakdown of one cfg-2 training step (HIP events): which layers cost what, at what TFLOP/s.
-    python tools/step_breakdown.py [bf16|f32] [B]"""
+"""Per-launch breakdown of one training step (HIP events): which layers cost what, at what TFLOP/s.
+    python tools/step_breakdown.py [bf16|f32] [B] [cfg2|cfg3|cfg1]"""
 import os
 import sys
 
@@ -12,10 +12,13 @@ from deepdenoiser_amd.architecture import Architecture  # noqa: E402
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-aj, tj = configs.cfg2_unet_kpcn(), configs.bench_training()
+cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+aj = {"cfg2": configs.cfg2_unet_kpcn, "cfg3": configs.cfg3_tiramisu, "cfg1": configs.cfg1_small_unet}[cfg]()
+tj = configs.bench_training()
+T = {"cfg2": 128, "cfg3": 256, "cfg1": 64}[cfg]
 arch = Architecture(aj, device="cuda", dtype=dtype, seed=2)
-prog = arch.program(B, 128, 128, training_json=tj)
-feats, labels = synthetic_inputs(arch, B, 128, 128, "cuda", 1)
+prog = arch.program(B, T, T, training_json=tj)
+feats, labels = synthetic_inputs(arch, B, T, T, "cuda", 1)
 prog.set_inputs(feats, labels)
 for _ in range(2):
     prog.train_step()
