@@ -34,6 +34,15 @@ def test_invalid_arguments_return_status_not_exception(lib):
     w = _lib.WgradArgs()
     assert lib.dd_conv_wgrad(ctypes.byref(w), None) == -1
     assert lib.dd_adam_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 1.0, None) == -1
+    # data augmentation: the reference refuses to flip world-space normals (DataAugmentation.py:22-23) and needs square tiles to rotate
+    src, dst, draws = ctypes.c_void_p(16), ctypes.c_void_p(32), ctypes.c_void_p(64)      # never dereferenced: validation fails first
+    assert lib.dd_augment(src, dst, 3, 1, 8, 8, draws, _lib.AUG_NORMAL, 1, 0, 0, 0, None) == -1
+    assert b"normals" in lib.dd_last_error()
+    assert lib.dd_augment(src, dst, 3, 1, 8, 12, draws, _lib.AUG_RGB, 0, 1, 0, 0, None) == -1
+    assert b"square" in lib.dd_last_error()
+    assert lib.dd_augment(src, dst, 2, 1, 8, 8, draws, _lib.AUG_PLAIN, 0, 0, 0, 0, None) == -1
+    assert lib.dd_loss_mask_sums(None, 1, 8, 8, None, None) == -1
+    assert lib.dd_maxpool_fwd(None, 8, None, 8, None, 8, 1, 8, 8, 3, 2, 1, _lib.DD_BF16, None) == -1
 
 
 def test_struct_sizes_match_header(lib):
