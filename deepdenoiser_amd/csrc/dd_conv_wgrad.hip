@@ -486,6 +486,19 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   for (int t = 0; t < TW; ++t)
 #pragma unroll
     for (int j = 0; j < NPW; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // lane-dependent part of every fragment address (see the tile loop): pixel offset of this lane within a transpose read, its slot, its half
+  int pbase[8], qbase[NPW][2];
+  {
+    const int t16 = lane & 15, gq = lane >> 4, sub = t16 & 3;
+    const int yl = gq >> 1, xl = (gq & 1) * 8 + (t16 >> 2), halfb = (sub & 1) * 8;
+    const int pl = yl * PW + xl, ql = yl * DD_TILE + xl;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pbase[c] = pl * DD_LDS_ROW + (((mi * 2 + (sub >> 1)) ^ ((pl + c) & 7)) << 4) + halfb;
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) qbase[j][h] = ql * DD_LDS_ROW + ((((nj + j) * 2 + (sub >> 1)) ^ ((ql + 4 * h) & 7)) << 4) + halfb;
+  }
   float bsum[NPW] = {0.f, 0.f};     // dy column sums of channels (nj + jj)*16 + lane&15 over this lane's pixels (bias_wave only)
 
   {
@@ -511,24 +524,57 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
     // (y*16 + x) & 7 are periodic in y with period 4 / 1), so the fragment addresses of iteration kp are those of iteration 0 plus kp * 4
     // rows: a few dozen address registers instead of one per step.  (1x1: 8 steps in all, fully unrolled.)
     constexpr int PADV = 4 * PW * DD_LDS_ROW, QADV = 4 * DD_TILE * DD_LDS_ROW;
-    uint4 bq[2][NPW], ap[3];
-    auto p_frag = [&](const char* pt, int hs) {      // hs = step within the iteration (may run 1-2 steps into the next one)
+    constexpr int RING = MODE == 0 ? 6 : 3, AHEAD = RING - 1;      // x fragments are read AHEAD steps before use (HSTEP % RING == 0)
+    uint4 bq[2][NPW], ap[RING];
+    // Fragment addresses.  A lane's pixel for a read at tile position C (= row*PW + dx, a compile-time constant) is pl + C, so its byte
+    // address is  tile + [pl*128 + ((slot ^ ((pl + (C & 7)) & 7)) << 4) + half]  +  C*128 : eight lane-dependent bases (C & 7) plus an
+    // immediate.  Left to itself hipcc materialises one address register per read (~100 VGPRs), which is what capped the read-ahead.
+    const char* pb[8];
+    const char* qb[NPW][2];
+    auto set_bases = [&](const char* pt, const char* qt) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pb[c] = pt + pbase[c];
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) { qb[j][0] = qt + qbase[j][0]; qb[j][1] = qt + qbase[j][1]; }
+    };
+    auto tr_pair = [&](const char* a0, const char* a1) {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
+      uint4 v;
+      v.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+      v.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+      v.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+      v.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      return v;
+    };
+    auto p_frag = [&](const char* pt, int hs) {      // hs = step within the iteration (may run AHEAD steps into the next one)
       const int k2 = hs / TW, i = hs - k2 * TW;
-      const int t = MODE == 1 ? min(tbase + i, 8) : i;
-      const int dy = HALO ? (t * 11) >> 5 : 0, dx = HALO ? t - 3 * dy : 0;      // t / 3, t % 3 for t < 9
-      uint4 v = frag_tr_bf16(pt, 2 * k2 + dy, PW, dx, mi, lane);
+      uint4 v;
+      if constexpr (MODE == 1) {                     // runtime tap: generic address arithmetic
+        const int t = min(tbase + i, 8);
+        const int dy = (t * 11) >> 5, dx = t - 3 * dy;                       // t / 3, t % 3 for t < 9
+        v = frag_tr_bf16(pt, 2 * k2 + dy, PW, dx, mi, lane);
+      } else {
+        const int dy = HALO ? i / 3 : 0, dx = HALO ? i % 3 : 0;
+        const int c0 = (2 * k2 + dy) * PW + dx;
+        v = tr_pair(pb[c0 & 7] + c0 * DD_LDS_ROW, pb[(c0 + 4) & 7] + (c0 + 4) * DD_LDS_ROW);
+      }
       if (IN_RELU) v = relu16<T>(v);
       return v;
+    };
+    auto q_frag = [&](const char* qt, int row, int j) {
+      if constexpr (MODE == 1) return frag_tr_bf16(qt, row, DD_TILE, 0, nj + j, lane);
+      else return tr_pair(qb[j][0] + row * DD_TILE * DD_LDS_ROW, qb[j][1] + (row * DD_TILE + 4) * DD_LDS_ROW);
     };
     auto body = [&](int kp, int hs, const char* pt, const char* qt) {
       const int k2 = hs / TW, i = hs - k2 * TW;
       const int g = MODE == 2 ? kp * HSTEP + hs : hs;               // ring position (a compile-time constant at every call)
-      ap[(g + 2) % 3] = p_frag(pt, hs + 2);                         // the last two of the tile read past it: never used
+      ap[(g + AHEAD) % RING] = p_frag(pt, hs + AHEAD);               // the last AHEAD of the tile read past it: never used
       if (TW >= NPW) {
-        if (i < NPW) bq[(k2 + 1) & 1][i] = frag_tr_bf16(qt, 2 * (k2 + 1), DD_TILE, 0, nj + i, lane);
+        if (i < NPW) bq[(k2 + 1) & 1][i] = q_frag(qt, 2 * (k2 + 1), i);
       } else {
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) bq[(k2 + 1) & 1][j] = frag_tr_bf16(qt, 2 * (k2 + 1), DD_TILE, 0, nj + j, lane);
+        for (int j = 0; j < NPW; ++j) bq[(k2 + 1) & 1][j] = q_frag(qt, 2 * (k2 + 1), j);
       }
 #ifndef DD_EXP_NO_PIECE
       // the NP DMA pieces of the next tile, spread evenly over the NSTEP steps (indices are compile-time constants at every call: a
@@ -551,23 +597,27 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) acc[i][j] = mfma_bf16(ap[g % 3], bq[k2 & 1][j], acc[i][j]);
+      for (int j = 0; j < NPW; ++j) acc[i][j] = mfma_bf16(ap[g % RING], bq[k2 & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     };
+    set_bases(ptile, qtile);
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) bq[0][j] = frag_tr_bf16(qtile, 0, DD_TILE, 0, nj + j, lane);
-    ap[0] = p_frag(ptile, 0);
-    ap[1] = p_frag(ptile, 1);
+    for (int j = 0; j < NPW; ++j) bq[0][j] = q_frag(qtile, 0, j);
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) ap[i] = p_frag(ptile, i);
     if constexpr (MODE == 2) {
 #pragma unroll
-      for (int kp = 0; kp < 4; ++kp)
+      for (int kp = 0; kp < 4; ++kp) {
+        set_bases(ptile + kp * PADV, qtile + kp * QADV);
 #pragma unroll
         for (int hs = 0; hs < HSTEP; ++hs) body(kp, hs, ptile + kp * PADV, qtile + kp * QADV);
+      }
     } else {
 #pragma unroll 1
       for (int kp = 0; kp < 4; ++kp) {
         const char* pt = ptile + kp * PADV;
         const char* qt = qtile + kp * QADV;
+        set_bases(pt, qt);
 #pragma unroll
         for (int hs = 0; hs < HSTEP; ++hs) body(kp, hs, pt, qt);
       }
