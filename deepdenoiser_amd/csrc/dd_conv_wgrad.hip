@@ -726,7 +726,12 @@ static bool dma_enabled() {
 
 template <typename T>
 int dispatch(const WgradP& p, hipStream_t stream) {
-  if (sizeof(T) == 2 && (p.taps == 9 || p.taps == 1) && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && dma_enabled()) { WgradP q = p; return launch_dma(q, stream); }
+  // (more than 32 channel-slice pairs -- > ~360 x 360 channels, Tiramisu transitions with wide filters -- do not fit the kernel's split table:
+  //  those launches take the register-staged kernel below)
+  if (sizeof(T) == 2 && (p.taps == 9 || p.taps == 1) && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && p.mslices * p.nslices <= 32 && dma_enabled()) {
+    WgradP q = p;
+    return launch_dma(q, stream);
+  }
   switch (p.taps) {
     case 9: return launch<T, 9>(p, stream);
     case 4: return launch<T, 4>(p, stream);

@@ -59,6 +59,7 @@ CONV_CASES = [
     (1, 24, 1, 16, 16, True, False, False, False),
     (3, 3, 16, 24, 24, True, False, False, False),       # cfg-1 first layer
     (1, 320, 320, 8, 8, False, True, False, False),      # Tiramisu transition-down
+    (1, 400, 400, 8, 8, False, True, False, False),      # 7 x 7 channel-slice pairs: the weight gradient leaves the LDS-DMA kernel's split table
 ]
 
 

@@ -4,7 +4,7 @@ from deepdenoiser_amd import configs
 from deepdenoiser_amd.architecture import Architecture
 from deepdenoiser_amd.training import Trainer
 from bench import synthetic_inputs
-for name, aj, B in [("cfg3 tiramisu F=[16,24,32]", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 8), ("cfg3 tiramisu F=[64,96,128]", configs.cfg3_tiramisu(), 4), ("cfg1 small unet", configs.cfg1_small_unet(), 64)]:
+for name, aj, B in [("cfg3 tiramisu F=[16,24,32]", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 8), ("cfg3 tiramisu F=[64,96,128] (heavy)", configs.cfg3_tiramisu(filters=(64, 96, 128)), 2), ("cfg1 small unet", configs.cfg1_small_unet(), 64)]:
     arch = Architecture(aj, device="cuda", dtype="bf16", seed=2)
     H = 64 if "cfg1" in name else 256
     tr = Trainer(arch, configs.bench_training(), B, H, H)
