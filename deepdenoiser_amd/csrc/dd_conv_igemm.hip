@@ -7,16 +7,18 @@
 // Mapping.  GEMM: D[cout][pixel] = sum_{tap, cin} Wp[tap][cout][cin] * X[pixel (+) tap][cin].
 //   "A" operand = packed weights (rows = cout), "B" operand = pixels (cols): after the MFMA every lane holds 4 CONSECUTIVE
 //   output channels of one pixel -> packed 8/16-byte NHWC stores with the bias/residual/ReLU/mask/accumulate epilogue fused.
-// Schedule (v2: persistent + software pipelined).  One workgroup (4 waves, one per SIMD) per CU walks a strided list of
-//   16x16-pixel tiles for a fixed block of NT*16 output channels.  A "unit" = one 128-byte K-slice (64 bf16 / 32 f32
-//   channels) of one tile: its (16+2)^2 halo patch is staged in LDS ONCE and reused by all 9 taps.  While the MFMAs of
-//   unit u run, the global loads of unit u+1's patch are already in flight into registers (written to the other LDS
-//   buffer after the compute, one barrier per unit).  Weights: if all (tap, slice) slabs of the layer fit next to the two
-//   patch buffers they are loaded ONCE per workgroup and stay resident (no per-tap traffic or barriers at all: 288 MFMAs
-//   per wave back to back for a 64->64 layer); otherwise the slab of the next tap is register-prefetched during the
-//   current tap's MFMAs (one barrier per tap, latency hidden).
-// LDS rows are 128 B with a 16-byte-slot XOR swizzle (dd_common.h: lds_off) => ds_read_b128 fragment reads are
-// bank-conflict free.
+// Schedule.  Persistent workgroups (one per CU) walk an XCD-local list of 16x16-pixel tiles for a fixed block of NT*16 output channels.
+//   A "unit" = one 128-byte K-slice (64 bf16 / 32 f32 channels) of one tile: its (16+2)^2 halo patch is staged in LDS ONCE and reused
+//   by all 9 taps.  Two kernels:
+//   * conv_igemm_ws_kernel (bf16, NT <= 4, weights LDS-resident -- every bf16 layer of the shipped configurations): 8 waves; waves 0-3
+//     only read fragments and issue MFMAs and park the finished tile in an LDS stage, waves 4-7 prefetch the next patch into registers,
+//     drain the previous tile's stage to HBM (bias / residual / ReLU / mask / accumulate fused) and write the next patch to LDS.  Two
+//     barriers per unit; 288 MFMAs per MFMA wave back to back for a 64->64 layer.
+//   * conv_igemm_kernel (f32 parity path and anything the above does not take): 4 waves doing both jobs, the next patch's global loads
+//     in flight during the MFMAs; weights resident when they fit, otherwise the next tap's slab is register-prefetched during the current
+//     tap's MFMAs.
+// LDS rows are 128 B with a 16-byte-slot XOR swizzle (dd_common.h: lds_off / lds_pix_off) => ds_read_b128 fragment reads are
+// bank-conflict free (SQ_LDS_BANK_CONFLICT = 7 % of SQ_LDS_IDX_ACTIVE, all from the stage).
 #include <stdlib.h>
 
 #include "dd_common.h"

@@ -17,8 +17,10 @@
 // patch is staged once and reused by the 9 taps.  f32 path: exact-f32 MFMA 16x16x4, one element per lane (ds_read_b32).
 // A workgroup owns one (m-slice, n-slice) of 128 B worth of channels each, ALL taps, and a strided subset of the
 // 16x16 pixel tiles (split-K); partial results are added with one fp32 atomic per element at the end.
-// The bias gradient costs no extra pass over the gradient tensor: every thread sums the vectors it stages anyway.
+// The bias gradient costs no extra pass over the gradient tensor: it is summed from data the kernel holds anyway.
 // All global loads are unconditional (invalid vectors read a zero page): a branch per vector serialises them.
+// Two kernels: wgrad_dma_kernel (bf16 3x3 and 1x1 layers: LDS-DMA, double-buffered tiles, 8 waves -- see its header) and wgrad_kernel (f32,
+// the 2x2 gather of the transpose convolutions, bias_mode 2, very wide layers: tiles staged through registers, next tile prefetched).
 #include <stdlib.h>
 
 #include "dd_common.h"
