@@ -194,12 +194,24 @@ __device__ __forceinline__ void slab_store(char* lds, const uint4 (&reg)[(NT + 1
   }
 }
 
+// Half slabs.  The last K-slice of a layer with an odd number of 64-byte K chunks (K = 32, 96, ...) carries only 4 slots per weight row.
+// The wave-specialised kernel stores those slabs with 64-byte rows: a 96 -> 96 layer then keeps 48 output channels resident (83 KiB)
+// next to the patch and the stage, i.e. 2 channel blocks instead of 3 (the patch is staged once per channel block).
+// Slot s of row r sits at physical slot s ^ ((r >> 3 & 1) << 1): the 16 lanes of a ds_read_b128 service group (rows 0-3 + 12-15 of one
+// slot, rows 4-11 of its neighbour) then cover 16 distinct 16-byte bank groups.
+__device__ __forceinline__ int lds_off64(int row, int slot) { return row * (DD_LDS_ROW / 2) + ((slot ^ (((row >> 3) & 1) << 1)) << 4); }
+// byte offset of slab (tap, slice) from the weight base; `half_last`: the last slice uses half slabs
+__device__ __forceinline__ int slab_off(int tap, int slice, int taps, int nslices, int wb, bool half_last) {
+  return (half_last && slice == nslices - 1) ? slice * taps * wb + tap * (wb / 2) : (slice * taps + tap) * wb;
+}
+
 // Every (tap, slice) weight slab of this workgroup's channel block -> LDS, once per launch.  BATCH 16-byte vectors per thread are in
 // flight before the first is stored: staging one slab at a time costs one full memory round trip per slab, and with every
 // workgroup of the launch doing it at once that was 34 us of a 63 us launch (64->64 3x3, 18 slabs; tools/phase_profile.py).
-template <typename T, int NT, int NTHREADS, int BATCH>
+template <typename T, int NT, int NTHREADS, int BATCH, bool HALF_LAST = false>
 __device__ __forceinline__ void stage_weights(char* wbase, const T* __restrict__ Wp, const ConvP& p, int n0, int nslices, int tid) {
   constexpr int KC = DD_LDS_ROW / (int)sizeof(T), ROWS = NT * 16, WB = ROWS * DD_LDS_ROW;
+  const bool half_last = HALF_LAST && (p.kchunks & 1);
   const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
   const int total = p.taps * nslices * ROWS * 8;
   for (int base = 0; base < total; base += NTHREADS * BATCH) {
@@ -220,7 +232,10 @@ __device__ __forceinline__ void stage_weights(char* wbase, const T* __restrict__
       const int v = base + b * NTHREADS + tid;
       const int slot = v & 7, r = v >> 3;
       const int row = r % ROWS, sidx = r / ROWS;
-      if (v < total) *reinterpret_cast<uint4*>(wbase + sidx * WB + lds_off(row, slot)) = reg[b];
+      const int slice = sidx / p.taps, tap = sidx - slice * p.taps;
+      const bool half = half_last && slice == nslices - 1;
+      char* slab = wbase + slab_off(tap, slice, p.taps, nslices, WB, half_last);
+      if (v < total && !(half && slot >= 4)) *reinterpret_cast<uint4*>(slab + (half ? lds_off64(row, slot) : lds_off(row, slot))) = reg[b];
     }
   }
 }
@@ -254,7 +269,7 @@ __device__ __forceinline__ TileWalk tile_walk(const ConvP& p) {
 // order the MFMAs need them (w0, p0..p3, w1..).  The interleave is pinned with sched_barrier(0): left alone -- and also with
 // sched_group_barrier, which fixes only HOW MANY reads go between MFMAs, not WHICH -- hipcc issues each weight fragment 2 MFMAs
 // before its use, and with one MFMA wave per SIMD every such read stalls the matrix pipe (measured 45 vs 16 cycles per MFMA).
-template <typename T, int NT, int PH, int NTAPS, int NCH>
+template <typename T, int NT, int PH, int NTAPS, int NCH, bool WHALF = false>
 __device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* patch, int shift_y, int shift_x, const char* wslab0, int wslab_stride,
                                           int tap_first, int wave, int q, int li) {
   constexpr int STEPS = NTAPS * NCH, NLOAD = 4 + NT, NMMA = 4 * NT;
@@ -270,7 +285,7 @@ __device__ __forceinline__ void mma_phase(f32x4_t (&acc)[NT][4], const char* pat
       bf[s & 1][r] = *reinterpret_cast<const uint4*>(patch + lds_pix_off(wave * 4 + r + dy + shift_y, li + dx + shift_x, PH, slot));
     } else {
       const int j = i == 0 ? 0 : i - 4;
-      af[s & 1][j] = *reinterpret_cast<const uint4*>(wslab0 + ti * wslab_stride + lds_off(j * 16 + li, slot));
+      af[s & 1][j] = *reinterpret_cast<const uint4*>(wslab0 + ti * wslab_stride + (WHALF ? lds_off64(j * 16 + li, slot) : lds_off(j * 16 + li, slot)));
     }
   };
 #pragma unroll
@@ -567,10 +582,11 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   const unsigned long long k_t0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
 #endif
 
-  stage_weights<T, NT, 512, 9>(wbase, Wp, p, n0, nslices, tid);   // all 8 waves; made visible by the roles' first barrier
+  stage_weights<T, NT, 512, 9, true>(wbase, Wp, p, n0, nslices, tid);   // all 8 waves; made visible by the roles' first barrier
+  const bool half_last = (p.kchunks & 1) != 0;      // the last K-slice is stored as half slabs
   // The bias lives in LDS too: re-reading it from global memory at every tile start put a full (loaded-machine) memory latency
   // in front of each tile's first MFMA -- half of the launch time.
-  float* bias_lds = reinterpret_cast<float*>(wbase + p.taps * nslices * WB);
+  float* bias_lds = reinterpret_cast<float*>(wbase + p.taps * nslices * WB - (half_last ? p.taps * (WB / 2) : 0));
   if (tid < NT * 16) {
     const int n = n0 + tid;
     const int bi = pixshuf ? n % cout : n;
@@ -598,10 +614,10 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
           for (int r = 0; r < 4; ++r) acc[j][r] = bv;
         }
       }
-      const char* w0 = wbase + (slice * p.taps + tap0) * WB;
+      const char* w0 = wbase + slab_off(tap0, slice, p.taps, nslices, WB, half_last);
       PHASE_T(m0);
       if (nch == 2) mma_phase<T, NT, PH, INNER, 2>(acc, patch, 0, 0, w0, WB, tap0, w4, q, li);
-      else mma_phase<T, NT, PH, INNER, 1>(acc, patch, 0, 0, w0, WB, tap0, w4, q, li);
+      else mma_phase<T, NT, PH, INNER, 1, true>(acc, patch, 0, 0, w0, WB / 2, tap0, w4, q, li);      // nch == 1 <=> the half-slab slice
       PHASE_T(m1);
       __syncthreads();   // bar1: patch consumed by every MFMA wave; stage drained by the I/O waves
       PHASE_T(m2);
@@ -781,9 +797,16 @@ int launch(const ConvP& p, int nslabs, hipStream_t stream) {
   return DD_OK;
 }
 
+// bytes of resident weights in the wave-specialised kernel: full 128-byte-row slabs, half slabs for an odd last K-slice
+static size_t ws_weight_bytes(const ConvP& p, int nt) {
+  const int nslices = (p.kchunks + 1) / 2;
+  const size_t wb = (size_t)nt * 16 * DD_LDS_ROW;
+  return (size_t)p.taps * nslices * wb - ((p.kchunks & 1) ? (size_t)p.taps * (wb / 2) : 0);
+}
+
 template <int NT, bool HALO>
 int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
-  const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + (size_t)nslabs * NT * 16 * DD_LDS_ROW + NT * 16 * sizeof(float);
+  const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, NT) + NT * 16 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<NT, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -821,7 +844,7 @@ int launch_nt(const ConvP& p, hipStream_t stream) {
   const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
   const bool resident = patch + (size_t)nslabs * NT * 16 * DD_LDS_ROW <= LDS_BUDGET;
   if constexpr (sizeof(T) == 2 && NT <= 4) {
-    const size_t ws_lds = patch + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + (size_t)nslabs * NT * 16 * DD_LDS_ROW;
+    const size_t ws_lds = patch + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, NT) + NT * 16 * sizeof(float);
     if (ws_enabled() && ws_lds <= 160 * 1024) return halo ? launch_ws<NT, true>(p, nslabs, stream) : launch_ws<NT, false>(p, nslabs, stream);
   }
   if (halo) return resident ? launch<T, NT, true, true>(p, nslabs, stream) : launch<T, NT, true, false>(p, nslabs, stream);
@@ -844,21 +867,22 @@ static int conv_policy_min_resident_nt() {
 template <typename T>
 int dispatch(ConvP& p, hipStream_t stream) {
   const int tiles_n = p.n_pad / 16;
-  static const int allowed[] = {8, 6, 4, 2, 1};
-  int cands[5], nc = 0;
+  static const int allowed[] = {8, 6, 4, 3, 2, 1};
+  int cands[6], nc = 0;
   for (int c : allowed) if (tiles_n % c == 0) cands[nc++] = c;
   const bool halo = p.taps == 9;
   const int nslabs = p.taps * ((p.kchunks + 1) / 2);
   const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
   int pick = 0;   // widest
-  // bf16: the wave-specialised kernel (NT <= 4, resident weights) beats the plain one even when that means more channel blocks -- the
-  // 1x1 / 2x2 layers (no halo, tiny weights) never take a wider block, and a 3x3 layer may go down to NT = 1 to keep its weights
-  // resident (192 -> 96: 6 blocks of 16 channels, measured +3.8 % on the whole step against the streamed NT = 6 launch).
+  // bf16: the wave-specialised kernel (NT <= 4, resident weights) beats the plain one even when that means more channel blocks: no bf16
+  // layer takes a wider block, and a 3x3 layer may go down to NT = 1 to keep its weights resident (192 -> 96: 6 blocks of 16 channels,
+  // measured +3.8 % on the whole step against the streamed NT = 6 launch).
   const bool ws_ok = sizeof(T) == 2 && ws_enabled();
   const int min_nt = ws_ok ? 1 : conv_policy_min_resident_nt();
   for (int i = 0; i < nc; ++i)
-    if (cands[i] >= min_nt && !(ws_ok && cands[i] > 4 && p.taps != 9) &&
-        patch + (sizeof(T) == 2 && cands[i] <= 4 && ws_enabled() ? (size_t)DD_TILE * DD_TILE * DD_LDS_ROW : 0) + (size_t)nslabs * cands[i] * 16 * DD_LDS_ROW <= LDS_BUDGET + 2048) { pick = i; break; }
+    if (cands[i] >= min_nt && !(ws_ok && cands[i] > 4) &&
+        patch + (ws_ok && cands[i] <= 4 ? (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, cands[i]) + cands[i] * 64
+                                         : (size_t)nslabs * cands[i] * 16 * DD_LDS_ROW) <= (ws_ok && cands[i] <= 4 ? (size_t)160 * 1024 : LDS_BUDGET + 2048)) { pick = i; break; }
   // keep every CU busy when the pixel grid is small
   while (pick + 1 < nc && cands[pick] > 2 && (long)p.total_tiles * (tiles_n / cands[pick]) < 256) ++pick;
   const int nt = cands[pick];
@@ -867,6 +891,7 @@ int dispatch(ConvP& p, hipStream_t stream) {
     case 8: return launch_nt<T, 8>(p, stream);
     case 6: return launch_nt<T, 6>(p, stream);
     case 4: return launch_nt<T, 4>(p, stream);
+    case 3: return launch_nt<T, 3>(p, stream);
     case 2: return launch_nt<T, 2>(p, stream);
     default: return launch_nt<T, 1>(p, stream);
   }

@@ -52,6 +52,9 @@ CONV_CASES = [
     (3, 64, 96, 16, 16, True, False, False, True),
     (3, 192, 96, 16, 16, True, False, False, True),
     (3, 128, 128, 8, 8, True, False, False, True),
+    (3, 96, 96, 16, 16, True, False, False, True),      # odd number of 64-byte K chunks: half-slab weights, 48-channel blocks
+    (3, 96, 192, 16, 16, False, False, False, True),
+    (3, 32, 96, 20, 12, True, False, True, False),
     (3, 24, 24, 20, 28, False, True, True, False),      # compose-net residual block conv, ragged tile
     (1, 64, 25, 32, 32, True, False, False, True),      # AdjustNumberOfChannels
     (1, 25, 25, 32, 32, False, False, False, True),
