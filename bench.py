@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0          # HBM3E, same guide
 
 
 def synthetic_inputs(arch, B, H, W, device, seed):
@@ -266,6 +267,12 @@ def main():
                 "traffic_source": tr["source"] if tr else None, "algorithmic_bytes_per_launch": alg_bytes / n,
                 "launches_per_step": n, "avg_launch_us": 1e3 * ms / n,
                 "algorithmic_gflop_per_step": flops / 1e9,
+                # the same launches seen from the memory side: a 64->64 3x3 conv in bf16 moves 2*64*2 B per pixel for 2*9*64*64 flop,
+                # 288 flop/B against a ridge of 2500/8 = 312 flop/B, so the U-Net's widest layers sit AT the ridge and every
+                # narrower layer (24/25/32 channels) is HBM-bound: both fractions are reported, the larger one is the binding roof
+                "hbm_view": {"achieved": alg_bytes / n / (1e-3 * ms / n) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": alg_bytes / n / (1e-3 * ms / n) / 1e9 / PEAK_HBM_GBS,
+                             "flop_per_byte": flops / alg_bytes, "ridge_flop_per_byte": 1e3 * peak / PEAK_HBM_GBS},
                 "other_kernels_ms_per_step": {k: round(v[1], 3) for k, v in times.items() if k != fam}}
     if rank == 0:
         out = {
