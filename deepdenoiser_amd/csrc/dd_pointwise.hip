@@ -16,6 +16,41 @@ void dd_set_error(const char* fmt, ...) {
 extern "C" const char* dd_last_error(void) { return g_err; }
 extern "C" const char* dd_version(void) { return "libdd_hip 0.1 (gfx950)"; }
 
+// CRC-32C, slicing-by-8 (host only).
+namespace {
+struct Crc32cTables {
+  uint32_t t[8][256];
+  Crc32cTables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+  }
+};
+}  // namespace
+extern "C" int dd_crc32c(const void* data, size_t n, uint32_t crc, uint32_t* out) {
+  DD_REQUIRE((data || !n) && out, "dd_crc32c: null pointer");
+  static const Crc32cTables tab;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = tab.t[7][lo & 0xFF] ^ tab.t[6][(lo >> 8) & 0xFF] ^ tab.t[5][(lo >> 16) & 0xFF] ^ tab.t[4][lo >> 24] ^
+        tab.t[3][hi & 0xFF] ^ tab.t[2][(hi >> 8) & 0xFF] ^ tab.t[1][(hi >> 16) & 0xFF] ^ tab.t[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = tab.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  *out = ~c;
+  return 0;
+}
+
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
 static inline unsigned grid_for(long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
 

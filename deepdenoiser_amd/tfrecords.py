@@ -27,11 +27,35 @@ for _i in range(256):
     _TABLE.append(_c)
 
 
-def crc32c(data):
+_native = None     # dd_crc32c of libdd_hip.so (host code, slicing-by-8) once loaded; False if the library is not built
+
+
+def _crc32c_python(data):
     c = 0xFFFFFFFF
     for b in data:
         c = _TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+def crc32c(data):
+    """CRC-32C of a bytes-like object.  Multi-megabyte payloads (tiles, checkpoint tensors) go through the library's host routine;
+    the table loop above is the definition and the fallback for short inputs or a missing library."""
+    global _native
+    if len(data) >= 4096 and _native is not False:
+        if _native is None:
+            try:
+                from . import _lib
+                _native = _lib.load().dd_crc32c
+            except (RuntimeError, OSError):
+                _native = False
+        if _native:
+            import ctypes as C
+            out = C.c_uint32()
+            raw = bytes(data) if not isinstance(data, bytes) else data
+            if _native(raw, len(raw), 0, C.byref(out)) != 0:
+                raise RuntimeError("dd_crc32c failed")
+            return out.value
+    return _crc32c_python(data)
 
 
 def masked_crc32c(data):

@@ -233,6 +233,11 @@ int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, int B, int H,
 int dd_zero_unstuff(const void* dy, int lddy, void* dx, int lddx, const void* mask, int ldmask, int C, int B, int H, int W,
                     int accumulate, int dtype, dd_stream stream);
 
+/* ---- host-side helper (no device work): CRC-32C (Castagnoli) of `n` bytes, continuing from `crc` (0 to start).  The checksum of
+ * the reference's on-disk formats: TFRecord framing (TFRecordsCreator.py:233-252) and TensorFlow checkpoint bundles written by the
+ * Estimator (Training.py:944-1000 model_dir).  Returns the plain (unmasked) CRC through *out. */
+int dd_crc32c(const void* data, size_t n, uint32_t crc, uint32_t* out);
+
 /* ---- probes used by the test-suite to pin hardware fragment layouts the kernels rely on */
 int dd_probe_tr16(const uint16_t* lds_image_4096, const int32_t* lane_byte_addr_64, uint16_t* out_64x4, dd_stream stream);
 

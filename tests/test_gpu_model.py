@@ -301,3 +301,46 @@ def test_masked_mean_loss_terms_parity_f32():
         if float(go.abs().max()) > 0:
             errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
     print("masked-loss gradient rel-L2: median %.2e max %.2e" % (sorted(errs)[len(errs) // 2], max(errs)))
+
+
+def test_tf_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """save_variables -> load_variables into a differently initialised replica: identical forward (bit exact) and the same next
+    optimisation step (weights, Adam moments and step count restored; Training.py:1209-1232 model_dir semantics)."""
+    _need_gpu()
+    from deepdenoiser_amd import tf_checkpoint as TC
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.training import Trainer
+    aj, tj = configs.architecture(filters=(16, 24), convs=1), configs.training()
+    B, H, W = 2, 32, 32
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(oracle, B, H, W)
+    dev, devl = {k: v.cuda() for k, v in feats.items()}, {k: v.cuda() for k, v in labels.items()}
+
+    def trainer(seed):
+        arch = Architecture(aj, device="cuda", dtype="f32", seed=seed)
+        t = Trainer(arch, tj, B, H, W, use_graph=False)
+        t.program.set_inputs(dev, devl)
+        return arch, t
+
+    arch_a, ta = trainer(seed=2)
+    for _ in range(3):
+        ta.step()
+    prefix = TC.save_variables(arch_a, str(tmp_path), global_step=3)
+    arch_b, tb = trainer(seed=9)
+    assert not torch.equal(arch_a.params.values, arch_b.params.values)
+    info = TC.load_variables(arch_b, TC.latest_checkpoint(str(tmp_path)))
+    assert prefix == TC.latest_checkpoint(str(tmp_path)) and info["global_step"] == 3 and info["adam_step"] == 3
+    assert info["missing"] == [] and info["unused"] == []
+    for p in arch_a.params.params:
+        assert torch.equal(arch_a.params.value(p), arch_b.params.value(p)), p.name
+    ta.program.forward()
+    tb.program.forward()
+    torch.cuda.synchronize()
+    for da, db in zip(ta.program.prediction_dictionaries(), tb.program.prediction_dictionaries()):
+        for k in da:
+            assert torch.equal(da[k], db[k]), k
+    la, lb = float(ta.step()), float(tb.step())
+    torch.cuda.synchronize()
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    assert rel_l2(arch_b.params.values, arch_a.params.values) <= 1e-6        # only the summation order of the gradient atomics differs
+    assert rel_l2(arch_b.params.m, arch_a.params.m) <= 1e-5
