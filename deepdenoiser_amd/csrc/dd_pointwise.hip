@@ -974,9 +974,10 @@ extern "C" int dd_loss_mask_sums(const dd_loss_desc* desc, int B, int H, int W, 
 __global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, float inv_count, float inv_count_var, float grad_scale,
                                  float* __restrict__ loss_out) {
   __shared__ float red[256];
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   float loss = 0.f;
-  if (i < npix) {
+  // grid-stride: a few thousand workgroups walk all pixels, so the descriptor (kernel argument, ~1 KB of scalar loads per wave) and the
+  // block reduction are paid once per ~8 pixels of a thread instead of once per pixel
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % W), y = (int)((i / W) % H);
     for (int f = 0; f < d.n_features; ++f) {
       float g[3];
@@ -1030,7 +1031,7 @@ extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float
   DD_REQUIRE(desc->kind >= 1 && desc->kind <= 5, "dd_loss_head: unknown loss kind %d", desc->kind);
   const long npix = (long)B * H * W;
   const long npairs = (long)B * ((long)H * (W - 1) + (long)(H - 1) * W);
-  hipLaunchKernelGGL(loss_head_kernel, dim3(grid_for(npix)), dim3(256), 0, S(stream), *desc, npix, H, W, 1.f / (float)npix,
+  hipLaunchKernelGGL(loss_head_kernel, dim3(min(grid_for(npix), 2048u)), dim3(256), 0, S(stream), *desc, npix, H, W, 1.f / (float)npix,
                      npairs > 0 ? 1.f / (float)npairs : 0.f, grad_scale, loss_out);
   DD_LAUNCH_CHECK();
   return DD_OK;

@@ -461,6 +461,7 @@ class Graph:
             cell[0](stream)
         run.tag = tag
         run.info = None
+        run.origin = getattr(make, "__qualname__", "")      # which builder queued this launch (tools/step_breakdown.py)
         return run
 
     def finalize(self, seed=2):

@@ -41,3 +41,11 @@ for (tag, shape), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         continue
     print("%-12s %-48s %5d %9.1f %8.1f %8.1f" % (tag, shape, a[0], a[1], a[1] / a[0], a[2] / a[1] / 1e6 if a[1] else 0))
 print("total %.1f us;" % tot, {k: (v[0], round(v[1], 3)) for k, v in fam.items()})
+if "ops" in sys.argv:
+    print("non-conv launches in program order:")
+    for tag, info, us in ops:
+        pass
+    all_ops = list(prog.g.pack_ops) + list(prog.g.fwd_ops) + list(prog.g.bwd_ops)
+    for op, (tag, info, us) in zip(all_ops, ops):
+        if not tag.startswith("conv"):
+            print("  %-16s %-60s %8.1f us" % (tag, getattr(op, "origin", getattr(op, "__qualname__", "?")), us))
