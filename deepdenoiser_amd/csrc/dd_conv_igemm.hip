@@ -687,6 +687,28 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       const TileCoord tc = tile_coord(p, dtile);
       const bool interior = tc.y0 + DD_TILE <= p.H && tc.x0 + DD_TILE <= p.W;
       const long tile_pix = pixshuf ? ((long)tc.b * p.hout + 2 * tc.y0) * p.wout + 2 * tc.x0 : ((long)tc.b * p.hout + tc.y0) * p.wout + tc.x0;
+      if (M && !R && !accum && !pixshuf && e_n == ESLOTS) {
+        // The plain data-gradient drain (mask only).  The stores depend on the mask loads, and under load one memory round trip costs
+        // thousands of cycles: all 8 mask vectors of the tile are requested before the first is used -- one round trip per tile
+        // instead of one per 4 vectors (64->64 at 128^2: 223 -> 195 us per launch).  Only this case: with residual / accumulate
+        // operands 8 more vectors in flight spill, and so does keeping the 8 masks in flight ACROSS the next patch's loads (tried:
+        // 78 spilled VGPRs, every launch 30-50 % slower).
+        uint4 mv[ESLOTS];
+        int offv[ESLOTS];           // pixel offset from the tile origin, -1: outside the image
+#pragma unroll
+        for (int it = 0; it < ESLOTS; ++it) {
+          const int pixl = ((lane >> 3) + it * 8) & 63;
+          const bool ok = lane_ok && (interior || (tc.y0 + w4 * 4 + (pixl >> 4) < p.H && tc.x0 + (pixl & 15) < p.W));
+          offv[it] = ok ? e_pix[it] : -1;
+          mv[it] = *reinterpret_cast<const uint4*>(M + (tile_pix + max(offv[it], 0)) * p.ldmask + ch);
+        }
+#pragma unroll
+        for (int it = 0; it < ESLOTS; ++it) {
+          const uint4 o4 = mask_bf16x8(*reinterpret_cast<const uint4*>(stage + e_lds[it]), mv[it]);
+          if (offv[it] >= 0) *reinterpret_cast<uint4*>(Y + (tile_pix + offv[it]) * p.ldy + ch) = o4;
+        }
+        return;
+      }
 #pragma unroll
       for (int half = 0; half < ESLOTS; half += 4) {
         if (half >= e_n) break;                 // wave-uniform
