@@ -760,9 +760,11 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
       const int nnch = min(2, p.kchunks - 2 * nslice);
       PHASE_T(i0);
 #ifndef DD_EXP_NO_IO
-      // dgrad (mask fused into the drain): drain FIRST.  Loads return in order, so mask loads issued behind the next patch's loads make
-      // the drain wait for the whole patch; the patch loads still land well before the MFMA waves reach the barrier.
-      const bool drain_first = M != nullptr && pending >= 0;
+      // Which goes first, the previous tile's drain or the next patch's loads?  Loads return in order.  The mask-only drain asks for
+      // all its masks at once, so behind the patch loads it waits ONE round trip that the two share (64->64 dgrad: 195 -> 182 us).
+      // The other masked drains make two dependent round trips of their own (4 vectors each): they go first.
+      const bool mask_only = M && !R && !accum && !pixshuf && e_n == ESLOTS;
+      const bool drain_first = M != nullptr && pending >= 0 && !mask_only;
       if (drain_first) { drain(pending); pending = -1; }
       if (has_next) patch_load<T, HALO>(pre, plan, X, p, ntile, nslice, ntap0, nnch * 4, t256);
 #endif
