@@ -1,16 +1,16 @@
 set -x
-mkdir -p gpurun_out/r01g
+mkdir -p gpurun_out/r01h
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/r01g/tests.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r01g/smoke.txt 2>&1
-timeout 400 python bench.py > gpurun_out/r01g/bench.json 2> gpurun_out/r01g/bench.err
-timeout 300 python bench.py --no-cpu-baseline --host-inputs 2>/dev/null | tail -1 > gpurun_out/r01g/host_inputs.txt
-timeout 300 python bench.py --mode inference --batch 105 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r01g/inference.json
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r01g/prof -o r01g -- python bench.py --no-cpu-baseline > gpurun_out/r01g/prof.log 2>&1
-python tools/rocprof_summary.py $(ls gpurun_out/r01g/prof/*/*results.db gpurun_out/r01g/prof/*results.db 2>/dev/null | head -1) > gpurun_out/r01g/kernel_stats.txt 2>&1
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/r01h/tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r01h/smoke.txt 2>&1
+timeout 400 python bench.py > gpurun_out/r01h/bench.json 2> gpurun_out/r01h/bench.err
+timeout 300 python bench.py --no-cpu-baseline --host-inputs 2>/dev/null | tail -1 > gpurun_out/r01h/host_inputs.txt
+timeout 300 python bench.py --mode inference --batch 105 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r01h/inference.json
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r01h/prof -o r01h -- python bench.py --no-cpu-baseline > gpurun_out/r01h/prof.log 2>&1
+python tools/rocprof_summary.py $(ls gpurun_out/r01h/prof/*/*results.db gpurun_out/r01h/prof/*results.db 2>/dev/null | head -1) > gpurun_out/r01h/kernel_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c -d gpurun_out/r01g/pmc_$c -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > gpurun_out/r01g/pmc_$c.log 2>&1
-  python tools/pmc_family.py gpurun_out/r01g/pmc_$c conv_igemm wgrad_dma > gpurun_out/r01g/pmc_$c.txt 2>&1
+  timeout 600 rocprofv3 --pmc $c -d gpurun_out/r01h/pmc_$c -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > gpurun_out/r01h/pmc_$c.log 2>&1
+  python tools/pmc_family.py gpurun_out/r01h/pmc_$c conv_igemm wgrad_dma > gpurun_out/r01h/pmc_$c.txt 2>&1
 done
-rm -rf gpurun_out/r01g/prof gpurun_out/r01g/pmc_FETCH_SIZE gpurun_out/r01g/pmc_WRITE_SIZE
-cat gpurun_out/r01g/tests.txt gpurun_out/r01g/smoke.txt; cut -c1-220 gpurun_out/r01g/bench.json; cat gpurun_out/r01g/pmc_*.txt; head -5 gpurun_out/r01g/kernel_stats.txt
+rm -rf gpurun_out/r01h/prof gpurun_out/r01h/pmc_FETCH_SIZE gpurun_out/r01h/pmc_WRITE_SIZE
+cat gpurun_out/r01h/tests.txt gpurun_out/r01h/smoke.txt; cut -c1-220 gpurun_out/r01h/bench.json; cat gpurun_out/r01h/pmc_*.txt; head -5 gpurun_out/r01h/kernel_stats.txt
