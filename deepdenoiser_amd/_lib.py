@@ -21,7 +21,7 @@ SYMBOLS = (
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
-    "dd_augment", "dd_loss_mask_sums", "dd_crc32c",
+    "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles",
 )
 
 
@@ -146,6 +146,7 @@ def load():
     lib.dd_augment.argtypes = [vp, vp, i, i, i, i, vp, i, i, i, i, i, vp]
     lib.dd_loss_mask_sums.argtypes = [vp, i, i, i, vp, vp]
     lib.dd_crc32c.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.dd_extract_tiles.argtypes = [vp, i, i, i, i, vp, i, i, vp, i, vp]
     _lib = lib
     return lib
 

@@ -1078,6 +1078,33 @@ extern "C" int dd_stitch(const float* tiles, int tile_size, int ldt, float* fram
   return DD_OK;
 }
 
+// One workgroup row = one tile row: threads walk the T*C contiguous floats of the row (float4 when both sides allow it).
+__global__ void extract_tiles_kernel(const float* __restrict__ frame, int fw, int ldf, int C, float* __restrict__ tiles, int ts, int ldt,
+                                     const int* __restrict__ origins) {
+  const int tile = blockIdx.y, row = blockIdx.x;
+  const int oy = origins[2 * tile], ox = origins[2 * tile + 1];
+  const float* src = frame + ((long)(oy + row) * fw + ox) * ldf;
+  float* dst = tiles + ((long)tile * ts + row) * ts * ldt;
+  if (C == ldf && C == ldt && ((ts * C) & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+    const int n4 = ts * C / 4;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < ts * C; i += blockDim.x) {
+    const int x = i / C, c = i - x * C;
+    dst[(long)x * ldt + c] = src[(long)x * ldf + c];
+  }
+}
+extern "C" int dd_extract_tiles(const float* frame, int frame_h, int frame_w, int ldf, int C, float* tiles, int tile_size, int ldt,
+                                const int* origins_yx, int n_tiles, dd_stream stream) {
+  DD_REQUIRE(frame && tiles && origins_yx && n_tiles > 0 && C > 0 && C <= ldf && C <= ldt, "dd_extract_tiles: bad arguments");
+  DD_REQUIRE(tile_size > 0 && tile_size <= frame_h && tile_size <= frame_w, "dd_extract_tiles: tile %d does not fit the %dx%d frame", tile_size,
+             frame_h, frame_w);
+  hipLaunchKernelGGL(extract_tiles_kernel, dim3(tile_size, n_tiles), dim3(128), 0, S(stream), frame, frame_w, ldf, C, tiles, tile_size, ldt, origins_yx);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 __global__ void recombine_kernel(const dd_recombine_desc d, long npix) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= npix * 3) return;

@@ -45,13 +45,11 @@ class Predictor:
         NF = prog.NF
         origins = plan.windows()                                                              # row-major (Prediction.py:380-382)
         grid = [(hi, wi) for hi in range(plan.rows.count) for wi in range(plan.cols.count)]
-        ar = torch.arange(T, device=dev)
         chunks = []
         for start in range(0, plan.count, Bt):
             ids = list(range(start, min(start + Bt, plan.count)))
             pad = ids + [ids[-1]] * (Bt - len(ids))                                           # ragged last batch: repeat a tile, never stitched
-            yy = torch.tensor([origins[t][0] for t in pad], device=dev)[:, None, None] + ar[None, :, None]
-            xx = torch.tensor([origins[t][1] for t in pad], device=dev)[:, None, None] + ar[None, None, :]
+            oyx = torch.tensor([[origins[t][0], origins[t][1]] for t in pad], dtype=torch.int32, device=dev)     # dd_extract_tiles table
             table = (L.StitchEntry * (len(ids) * NF))()
             n = 0
             for f in range(NF):
@@ -61,7 +59,7 @@ class Predictor:
                     table[n] = L.StitchEntry(f * Bt + slot, cy0, cy1, cx0, cx1, f, plan.rows.offsets[hi], plan.cols.offsets[wi])
                     n += 1
             tdev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
-            chunks.append((yy, xx, tdev, n))
+            chunks.append((oyx, tdev, n))
         self._plans[key] = (plan, prog, chunks)
         return self._plans[key]
 
@@ -70,15 +68,24 @@ class Predictor:
         arch, lib = self.arch, self.lib
         dev = arch.device
         names = arch.required_source_names()
-        frame = {k: torch.as_tensor(features[k], dtype=torch.float32).to(dev) for k in names}
+        frame = {k: torch.as_tensor(features[k], dtype=torch.float32).to(dev).contiguous() for k in names}
         H, W = frame[names[0]].shape[0], frame[names[0]].shape[1]
         plan, prog, chunks = self._frame_plan(H, W)
         T, NF = plan.tile, prog.NF
         frames = torch.zeros((NF, H, W, 3), dtype=torch.float32, device=dev)
         prog.pack_weights()
         stream = prog.g.stream_ptr()
-        for yy, xx, tdev, n in chunks:
-            prog.set_inputs({k: frame[k][yy, xx] for k in names})        # one gather per pass: [Bt,T,T,C] halo tiles
+        feats = prog.head + arch.auxiliary_features
+        for f in feats:
+            fr = frame[Naming.source_feature_name(f.name, index=0)]
+            if fr.dim() != 3 or fr.shape[2] < f.number_of_channels or tuple(fr.shape[:2]) != (H, W):
+                raise ValueError("%s: expected a [%d,%d,>=%d] frame, got %s" % (f.name, H, W, f.number_of_channels, tuple(fr.shape)))
+        for oyx, tdev, n in chunks:
+            for f in feats:                                              # halo tiles straight into the program's input buffers
+                fr = frame[Naming.source_feature_name(f.name, index=0)]
+                raw = prog.raw[f.name]
+                L.check(lib.dd_extract_tiles(fr.data_ptr(), H, W, fr.shape[2], f.number_of_channels, raw.data_ptr(), T, raw.shape[3],
+                                             oyx.data_ptr(), oyx.shape[0], stream))
             self._forward(prog)
             tiles = prog.predictions[0]                                  # [NF*Bt, T, T, 3], feature-major
             L.check(lib.dd_stitch(tiles.ptr, T, 3, frames.data_ptr(), H, W, 3, 3, tdev.data_ptr(), n, stream))

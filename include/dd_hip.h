@@ -200,6 +200,12 @@ typedef struct { int tile; int crop_y0, crop_y1, crop_x0, crop_x1; int dst_img, 
 int dd_stitch(const float* tiles, int tile_size, int ldt, float* frames, int frame_h, int frame_w, int ldf, int C,
               const dd_stitch_entry* table, int n_entries, dd_stream stream);
 
+/* ---- inference tile extraction (Prediction.py:283-310: tiled_feature = feature[lower_h:upper_h, lower_w:upper_w] for every window
+ * of the plan): tiles[i] = frame[origin_y[i] : +tile_size, origin_x[i] : +tile_size, 0:C].  frame [frame_h, frame_w, ldf],
+ * tiles [n_tiles, tile_size, tile_size, ldt] fp32; origins: n_tiles (y, x) int pairs on the device. */
+int dd_extract_tiles(const float* frame, int frame_h, int frame_w, int ldf, int C, float* tiles, int tile_size, int ldt,
+                     const int* origins_yx, int n_tiles, dd_stream stream);
+
 /* ---- recombination (Prediction.py:443-481): image = sum_k color_k*(direct_k+indirect_k) + sum_j single_j ; also writes each
  * combined_k if combined[k] != NULL.  All tensors [npix, 3] fp32 contiguous. */
 typedef struct {

@@ -141,6 +141,16 @@ def test_full_hd_frame_survives_tiling_and_stitching_bit_exact(lib):
     yy = (ys[:, None, None] + ar[None, :, None]).cuda()
     xx = (xs[:, None, None] + ar[None, None, :]).cuda()
     tiles = frame[yy, xx].contiguous()                                                  # [209,128,128,3]
+    # the C-ABI extraction (Prediction.py:283-310) gives the same tiles, also for 1- and 4-channel frames with padded rows
+    oyx = torch.tensor(win, dtype=torch.int32).cuda()
+    got = torch.full_like(tiles, float("nan"))
+    L.check(lib.dd_extract_tiles(frame.data_ptr(), H, W, 3, 3, got.data_ptr(), T, 3, oyx.data_ptr(), len(win), None))
+    assert torch.equal(got, tiles)
+    wide = torch.randn(H, W, 4, generator=g).cuda()
+    for C in (1, 4):
+        out_c = torch.zeros(len(win), T, T, 8).cuda()
+        L.check(lib.dd_extract_tiles(wide.data_ptr(), H, W, 4, C, out_c.data_ptr(), T, 8, oyx.data_ptr(), len(win), None))
+        assert torch.equal(out_c[..., :C], wide[yy, xx][..., :C]) and float(out_c[..., C:].abs().max()) == 0.0
     table = (L.StitchEntry * len(win))()
     for i in range(len(win)):
         hi, wi = divmod(i, plan.cols.count)
