@@ -5,7 +5,7 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/r01h/t
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r01h/smoke.txt 2>&1
 timeout 400 python bench.py > gpurun_out/r01h/bench.json 2> gpurun_out/r01h/bench.err
 timeout 300 python bench.py --no-cpu-baseline --host-inputs 2>/dev/null | tail -1 > gpurun_out/r01h/host_inputs.txt
-timeout 300 python bench.py --mode inference --batch 105 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r01h/inference.json
+timeout 300 python bench.py --mode inference --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r01h/inference.json
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r01h/prof -o r01h -- python bench.py --no-cpu-baseline > gpurun_out/r01h/prof.log 2>&1
 python tools/rocprof_summary.py $(ls gpurun_out/r01h/prof/*/*results.db gpurun_out/r01h/prof/*results.db 2>/dev/null | head -1) > gpurun_out/r01h/kernel_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
