@@ -292,6 +292,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(aj, tj, H, W)
         print(json.dumps(out))
     if world > 1:
+        barrier()                      # rank 0 may still be timing single launches for the roofline: leave together
         dist.destroy_process_group()
 
 
