@@ -285,7 +285,9 @@ def main():
             "config": {"workload": "BASELINE config 2: U-Net [64,96,128]x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction, "
                                    "32-channel render-pass stack, %dx%d tiles, full training step (fwd+SMAPE loss+bwd+Adam)" % (H, W),
                        "tiles_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "hipgraph": not args.no_graph, "final_loss": loss, "inputs": "pinned host, copied every step" if args.host_inputs else "resident in HBM"},
+                       "hipgraph": not args.no_graph, "final_loss": loss,
+                       # a tile of the reference's example JSON is 17 SINGLE tuple passes through the network
+                       "example_json_tiles_per_s": world * B * args.steps / dt / 17.0, "inputs": "pinned host, copied every step" if args.host_inputs else "resident in HBM"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
