@@ -15,6 +15,7 @@ PyTorch provides device memory and streams only.
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -154,6 +155,21 @@ class ConvLayer:
         self.bias = ps.get(name + "/bias", (cout,))
         self._packed = {}
 
+    def packed_k_range(self, k0, kn):
+        """Forward operand of input channels [k0, k0 + kn) only (conv layers): the K-split of a conv over a channel concat."""
+        key = ("fwd", k0, kn)
+        if key in self._packed:
+            return self._packed[key]
+        assert self.kind == "conv" and 0 <= k0 and k0 + kn <= self.cin
+        g, cout = self.g, self.cout
+        chunk = 64 // _ESZ[g.dtype]
+        taps = self.k * self.k
+        n_pad, k_pad = round_up(cout, 16), round_up(round_up(kn, 8), chunk)
+        buf = torch.zeros(taps * n_pad * k_pad, dtype=_TORCH_DT[g.dtype], device=g.device)
+        g.register_pack(self.kernel, buf, taps, cout, kn, n_pad, k_pad, self.cin * cout, 1, cout, 0, src_offset=k0 * cout)
+        self._packed[key] = (buf, taps, n_pad, k_pad)
+        return self._packed[key]
+
     def packed(self, role):
         """role 'fwd' | 'dgrad' -> (buffer, taps, n_pad, k_pad); registers the pack launch on first use."""
         if role in self._packed:
@@ -197,16 +213,16 @@ class Graph:
         self._pack_records = []
 
     # ------------------------------------------------------------------ weight packing: every layer in ONE launch
-    def register_pack(self, kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip):
-        self._pack_records.append((kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip))
+    def register_pack(self, kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip, src_offset=0):
+        self._pack_records.append((kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip, src_offset))
         if not self.pack_ops:
             state = {}
 
             def pack_all(stream):
                 if state.get("n") != len(self._pack_records):   # (re)build the device table when layers were added
                     tab = (L.PackDesc * len(self._pack_records))()
-                    for i, (kern, b, tp, nn, kk, npad, kpad, s_t, s_n, s_k, fl) in enumerate(self._pack_records):
-                        tab[i] = L.PackDesc(self.params.value_ptr(kern), b.data_ptr(), tp, nn, kk, npad, kpad, fl, s_t, s_n, s_k)
+                    for i, (kern, b, tp, nn, kk, npad, kpad, s_t, s_n, s_k, fl, off) in enumerate(self._pack_records):
+                        tab[i] = L.PackDesc(self.params.value_ptr(kern) + 4 * off, b.data_ptr(), tp, nn, kk, npad, kpad, fl, s_t, s_n, s_k)
                     state["dev"] = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
                     state["n"] = len(self._pack_records)
                 L.check(self.lib.dd_pack_weights_batched(state["dev"].data_ptr(), state["n"], self.code, stream))
@@ -295,17 +311,35 @@ class Graph:
         return run
 
     # ------------------------------------------------------------------ differentiable ops
-    def conv(self, x, layer, relu=False, in_relu=False, res=None, out=None):
-        """tf.layers.conv2d(k x k, SAME) [+ residual] [+ ReLU]; `out` may be a channel view of a concat buffer."""
+    def conv(self, x, layer, relu=False, in_relu=False, res=None, out=None, split_at=None):
+        """tf.layers.conv2d(k x k, SAME) [+ residual] [+ ReLU]; `out` may be a channel view of a concat buffer.
+        split_at: x is the concat [x[:, :split_at] | x[:, split_at:]] (the U-Net skip concat).  With more than 128 input channels in
+        bf16 the 3x3 weights of a 32-channel block no longer fit LDS and the launch falls to 16-channel blocks (6 passes over the
+        input for 192 -> 96); the forward then runs as conv(first part) followed by conv(second part) + that partial sum as residual:
+        two launches with resident weights (192 -> 96 at 64^2, B=128: 371 -> ~250 us).  The backward is unchanged (one dgrad, one wgrad
+        over the whole concat)."""
         assert layer.kind == "conv" and x.C == layer.cin, (layer.name, x.C, layer.cin)
         y = out if out is not None else self.tensor(x.B, x.H, x.W, layer.cout, relu=relu)
         y.relu = relu
         assert y.C == layer.cout
         ps = self.params
-        wp, taps, n_pad, k_pad = layer.packed("fwd")
         flags = (L.OUT_RELU if relu else 0) | (L.IN_RELU if in_relu else 0)
-        self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, res, None, y,
-                                                     x.B, x.H, x.W, flags, nk=(layer.cout, layer.cin)), "conv_igemm"))
+        do_split = (split_at is not None and self.dtype == "bf16" and layer.k == 3 and res is None and layer.cin > 128
+                    and 0 < split_at < layer.cin and split_at % 8 == 0 and max(split_at, layer.cin - split_at) <= 128
+                    and os.environ.get("DD_CONV_SPLIT_CONCAT", "1") != "0")
+        if do_split:
+            xa, xb = x.view(0, split_at), x.view(split_at, layer.cin - split_at)
+            part = self.tensor(x.B, x.H, x.W, layer.cout, requires_grad=False)
+            wa, taps, n_pad, ka_pad = layer.packed_k_range(0, split_at)
+            wb, _, _, kb_pad = layer.packed_k_range(split_at, layer.cin - split_at)
+            self.fwd(self._defer(lambda: self._conv_call(xa, wa, taps, n_pad, ka_pad, ps.value_ptr(layer.bias), layer.cout, None, None, part,
+                                                         x.B, x.H, x.W, flags & L.IN_RELU, nk=(layer.cout, split_at)), "conv_igemm"))
+            self.fwd(self._defer(lambda: self._conv_call(xb, wb, taps, n_pad, kb_pad, None, 0, part, None, y,
+                                                         x.B, x.H, x.W, flags, nk=(layer.cout, layer.cin - split_at)), "conv_igemm"))
+        else:
+            wp, taps, n_pad, k_pad = layer.packed("fwd")
+            self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, res, None, y,
+                                                         x.B, x.H, x.W, flags, nk=(layer.cout, layer.cin)), "conv_igemm"))
 
         def backward():
             if not y.grad_written:

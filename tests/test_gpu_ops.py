@@ -78,7 +78,15 @@ def test_conv_non_square_batches(eng, k, cin, cout, H, W, B):
     _conv_case(eng, "f32", k, cin, cout, H, W, True, False, False, True, B=B)
 
 
-def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,split_at,H,W", [(192, 96, 96, 16, 16), (160, 64, 64, 20, 12)])
+def test_conv_over_skip_concat_runs_as_two_resident_launches(eng, dtype, cin, cout, split_at, H, W):
+    """conv(concat[a | b]) = conv_a(a) + conv_b(b): the forward of a > 128-channel 3x3 layer over a U-Net skip concat (engine.Graph.conv,
+    split_at); forward, data- and weight-gradients against the oracle as for every other layer (f32: the split is bf16-only, one launch)."""
+    _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, split_at=split_at)
+
+
+def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None):
     gen = _gen(k * 1000 + cin + cout)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=True)
@@ -91,7 +99,9 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
         res = g.tensor(B, H, W, cout, requires_grad=True)
         rv = representable(torch.randn(B, H, W, cout, generator=gen, dtype=torch.float64), dtype)
     lay = g.layer("t/conv2d", k, cin, cout)
-    y = g.conv(x, lay, relu=relu, in_relu=in_relu, res=res)
+    y = g.conv(x, lay, relu=relu, in_relu=in_relu, res=res, split_at=split_at)
+    if split_at is not None and dtype == "bf16":
+        assert len(g.fwd_ops) == 2, "the concat split did not engage"
     y.mark_grad_written()
     g.build_backward()
     g.finalize()
