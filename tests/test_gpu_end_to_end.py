@@ -1,0 +1,165 @@
+"""-m gpu: the path as a user of the reference walks it, every hop through this package:
+
+    <base>/training/training_<n>.tfrecords.gz + training.json   (TFRecordsCreator.py layout)      -> tfrecords.read_records / decode_example
+    data_augmentation block of the training JSON                  (Training.py:794-821)             -> DataAugmentation.apply  (dd_augment)
+    model_fn TRAIN branch                                         (Training.py:607-702)             -> Trainer.step            (HIP kernels)
+    model_directory checkpoint                                    (Training.py:1209-1232)           -> tf_checkpoint.save_variables / load_variables
+    a directory of per-pass .exr files -> tiles -> predict -> stitch (Prediction.py:223-441)        -> openexr.load_frame, Predictor.predict_frame
+    <Pass>.npy / Combined.npy                                     (Prediction.py:483-510)           -> openexr.save_predictions
+
+What is checked: the data arrive unchanged where no augmentation applies, the loss goes down on a learnable toy task, the restored
+model predicts bit-identically to the trained one, and the frame prediction equals the oracle's on the same weights (f32 gate 1e-4).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deepdenoiser_amd import configs, openexr, tf_checkpoint, tfrecords
+from deepdenoiser_amd.data_augmentation import DataAugmentation, DataAugmentationUsage
+from deepdenoiser_amd.naming import Naming
+from gpu_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+T = 32           # tile size of the miniature data set
+SPP = 16
+
+
+def _write_dataset(base, arch, n_files=2, per_file=4, seed=0):
+    """Tiles of smooth radiance: sources = target * (1 + noise), so that denoising is learnable in a few steps."""
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(base, "training"))
+    json.dump({"tiles_height_width": T, "number_of_sources_per_example": 1, "source_samples_per_pixel_list": [SPP]},
+              open(os.path.join(base, "training_%d.json" % SPP), "w"))
+    passes = {f.name: f.number_of_channels for f in arch.feature_predictions + arch.auxiliary_features if f.load_data}
+    targets = [f.name for f in arch.feature_predictions if f.load_data and f.is_target]
+    yy, xx = np.meshgrid(np.linspace(0, 1, T, dtype=np.float32), np.linspace(0, 1, T, dtype=np.float32), indexing="ij")
+    examples = []
+    for n in range(n_files):
+        records = []
+        for _ in range(per_file):
+            feats, clean = {}, {}
+            for name, ch in passes.items():
+                a, b, c = rng.random(3).astype(np.float32)
+                base_img = np.stack([(a + b * yy + c * xx) * (0.5 + 0.5 * k / max(ch, 1)) for k in range(ch)], axis=-1).astype(np.float32)
+                clean[name] = base_img
+                noisy = base_img * (1.0 + 0.3 * rng.standard_normal(base_img.shape).astype(np.float32))
+                feats[Naming.source_feature_name(name, samples_per_pixel=SPP, index=0)] = noisy.astype(np.float32).tobytes()
+            for name in targets:
+                feats[Naming.target_feature_name(name)] = clean[name].tobytes()
+            records.append(tfrecords.serialize_example(feats))
+            examples.append(feats)
+        tfrecords.write_records(os.path.join(base, "training", "training_%d.tfrecords.gz" % n), records)
+    return passes, targets, examples
+
+
+def _batches(base, passes, targets, batch):
+    st = tfrecords.read_settings(base, "training", SPP)
+    tile, spps = st["tiles_height_width"], st["source_samples_per_pixel_list"]
+    buf = []
+    for path in tfrecords.list_files(os.path.join(base, "training"), "training"):
+        for rec in tfrecords.read_records(path, verify_payload_crc=True):
+            src, tgt = tfrecords.decode_example(tfrecords.parse_example(rec), passes, tile, spps, [0], targets)
+            buf.append((src[SPP][0], tgt))
+            if len(buf) == batch:
+                feats = {Naming.source_feature_name(n, index=0): torch.from_numpy(np.stack([s[n] for s, _ in buf])).cuda() for n in passes}
+                labels = {Naming.target_feature_name(n): torch.from_numpy(np.stack([t[n] for _, t in buf])).cuda() for n in targets}
+                yield feats, labels
+                buf = []
+
+
+def test_dataset_to_checkpoint_to_frame(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.prediction import Predictor
+    from deepdenoiser_amd.training import Trainer
+    from oracle.model import OracleArchitecture
+
+    aj = configs.architecture(filters=(16, 24), convs=1, flag_mode="NONE")
+    tj = configs.training(learning_rate=2e-3)
+    tj["data_augmentation"] = {"use_rotate_90": True, "use_flip_left_right": False, "use_rgb_permutation": True, "use_normal_rotation": False}
+    B = 4
+    arch = Architecture(aj, device="cuda", dtype="f32", seed=2)
+    base = str(tmp_path / "data")
+    passes, targets, examples = _write_dataset(base, arch)
+
+    # ---- the reader hands back exactly what was written
+    first = next(_batches(base, passes, targets, B))
+    name0 = next(iter(passes))
+    want = np.frombuffer(examples[0][Naming.source_feature_name(name0, samples_per_pixel=SPP, index=0)], dtype="<f4").reshape(T, T, passes[name0])
+    assert np.array_equal(first[0][Naming.source_feature_name(name0, index=0)][0].cpu().numpy(), want)
+
+    # ---- train: 3 epochs over the 8 tiles, augmented on the device with one set of draws per tile
+    trainer = Trainer(arch, tj, B, T, T, use_graph=False)
+    usage = DataAugmentationUsage.from_training_json(tj)
+    gen = torch.Generator().manual_seed(0)
+    losses = []
+    for epoch in range(3):
+        for feats, labels in _batches(base, passes, targets, B):
+            for f in arch.feature_predictions + arch.auxiliary_features:       # passes that are generated, not loaded (Training.py:531-538)
+                if not f.load_data:
+                    value = 1.0 if f.feature_prediction_type == "COLOR" else 0.5
+                    feats[Naming.source_feature_name(f.name, index=0)] = torch.full((B, T, T, f.number_of_channels), value).cuda()
+                    if f.is_target:
+                        labels[Naming.target_feature_name(f.name)] = torch.full((B, T, T, f.number_of_channels), value).cuda()
+            feats, labels = DataAugmentation.apply(feats, labels, DataAugmentation.draw(B, gen), usage)
+            trainer.program.set_inputs(feats, labels)
+            losses.append(float(trainer.step()))
+    assert all(np.isfinite(losses)) and np.mean(losses[-2:]) < np.mean(losses[:2]), losses
+
+    # ---- checkpoint round trip through the Estimator's directory layout
+    model_dir = str(tmp_path / "model")
+    prefix = tf_checkpoint.save_variables(arch, model_dir, global_step=len(losses))
+    assert tf_checkpoint.latest_checkpoint(model_dir) == prefix
+    fresh = Architecture(aj, device="cuda", dtype="f32", seed=11)
+    predictor = Predictor(fresh, tile_size=T, tile_overlap_size=4, tiles_per_batch=8, use_graph=False)
+    H, W = 40, 72
+    predictor.prepare(H, W)
+    info = tf_checkpoint.load_variables(fresh, prefix, load_optimizer=False)
+    assert info["global_step"] == len(losses) and info["missing"] == []
+    for p, q in zip(arch.params.params, fresh.params.params):
+        assert p.name == q.name and torch.equal(arch.params.value(p), fresh.params.value(q))
+
+    # ---- a frame: one .exr per pass in a directory -> features -> halo tiles -> prediction -> stitched passes -> .npy
+    frame_dir = tmp_path / "frame_0001_16_0_0"
+    frame_dir.mkdir()
+    rng = np.random.default_rng(5)
+    for name, ch in passes.items():
+        img = rng.random((H, W, 3)).astype(np.float32)
+        if ch == 1:
+            img[...] = img[..., :1]
+        openexr.write_image(str(frame_dir / ("render_%s_0001.exr" % name)), img)
+    feats = openexr.load_frame(str(frame_dir), fresh)
+    out = predictor.predict_frame({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in feats.items()})
+    written = openexr.save_predictions(str(frame_dir), out)
+    assert any(p.endswith(".npy") for p in written) and all(os.path.exists(p) for p in written)
+
+    # the oracle with the same weights on the same frame, tile by tile with the reference's plan (float64)
+    from oracle import tiling_ref
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    probe = {k: torch.from_numpy(np.ascontiguousarray(v[:T, :T]))[None].double() for k, v in feats.items()}
+    oracle.predict(probe)                                            # creates the variables
+    ck = tf_checkpoint.read_checkpoint(prefix)
+    for name in list(oracle.vs.vars.keys()):
+        oracle.vs.vars[name].data.copy_(torch.from_numpy(np.array(ck[name])).double())
+    O = 4
+    t, o, hc, wc, windows = tiling_ref.plan(H, W, T, O)
+    assert (t, o) == (T, O)
+    frame64 = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in feats.items()}
+    per_tile = [[oracle.predict({k: v[None, lh:uh, lw:uw] for k, v in frame64.items()})[0] for (lh, uh, lw, uw) in row] for row in windows]
+    want = {}
+    for key in per_tile[0][0]:
+        rows = [[d[key][0].detach().numpy() for d in row] for row in per_tile]
+        want[key] = torch.from_numpy(np.asarray(tiling_ref.stitch(rows, H, W, T, O)))
+    checked = 0
+    for key, got in out.items():
+        if key in want:
+            assert tuple(got.shape) == tuple(want[key].shape) and rel_l2(got, want[key]) <= 1e-4, key
+            saved = np.load(os.path.join(str(frame_dir), key.split("/", 1)[1] + ".npy"))
+            assert np.array_equal(saved, got.cpu().numpy())
+            checked += 1
+    assert checked >= 1
