@@ -62,6 +62,8 @@ CASES = {
     "invert_before_multiscale": (configs.architecture(filters=(16, 16), convs=1, invert_after_multiscale=False, flag_mode="NONE",
                                                       combined={"Emission": {"Color": "Emission", "Direct": "", "Indirect": ""}}), 2, 32, 16),
     "tiramisu_multiscale": (configs.cfg3_tiramisu(filters=(16, 24, 32), convs=2), 1, 32, 32),
+    # tile sizes that are not multiples of the 16x16 workgroup tile at any scale (24x40 -> 12x20 -> 6x10), odd batch
+    "ragged_tile_three_scales": (configs.architecture(filters=(16, 16, 24), convs=1, flag_mode="NONE"), 3, 24, 40),
 }
 
 
@@ -107,7 +109,7 @@ def test_forward_parity_f32(case):
 
 
 @pytest.mark.parametrize("case", ["cfg1_small_unet_direct", "example_json_single_embedding", "cfg2_unet_kpcn_real_filters", "combined_tuples_kp3",
-                                  "tiramisu_multiscale"])
+                                  "tiramisu_multiscale", "ragged_tile_three_scales"])
 def test_training_step_parity_f32(case):
     """loss, every parameter gradient, and a 3-step Adam trajectory."""
     _need_gpu()
