@@ -159,7 +159,8 @@ def read_checkpoint(prefix, names=None, verify=True):
         if e.dtype not in _NP_OF_DT:
             continue                                # strings, resources, ...: nothing this model stores
         if e.shard_id not in shards:
-            shards[e.shard_id] = np.memmap("%s.data-%05d-of-%05d" % (prefix, e.shard_id, num_shards), dtype=np.uint8, mode="r")
+            path = "%s.data-%05d-of-%05d" % (prefix, e.shard_id, num_shards)
+            shards[e.shard_id] = (np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, dtype=np.uint8))     # (an empty file cannot be mapped)
         data = shards[e.shard_id]
         dt = _NP_OF_DT[e.dtype]
         count = int(np.prod(e.shape, dtype=np.int64)) if e.shape else 1
