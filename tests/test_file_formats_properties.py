@@ -51,3 +51,14 @@ def test_checkpoint_round_trip(tmp_path_factory, entries, seed, block):
     assert list(back) == sorted(tensors, key=lambda s: s.encode())
     for k, v in tensors.items():
         assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+
+
+@settings(max_examples=30, deadline=None)
+@given(examples=st.lists(st.dictionaries(st.text(min_size=1, max_size=30), st.binary(min_size=0, max_size=300), min_size=0, max_size=6), min_size=0, max_size=5),
+       gz=st.booleans())
+def test_tfrecord_examples_round_trip(tmp_path_factory, examples, gz):
+    from deepdenoiser_amd import tfrecords as R
+    path = str(tmp_path_factory.mktemp("rec") / ("t_0.tfrecords" + (".gz" if gz else "")))
+    R.write_records(path, [R.serialize_example(e) for e in examples])
+    got = [R.parse_example(r) for r in R.read_records(path, verify_payload_crc=True)]
+    assert got == examples
