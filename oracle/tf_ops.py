@@ -42,7 +42,7 @@ def conv2d_same(x, kernel_hwio, bias=None, relu=False):
     MultiScalePrediction.py:64-66,73-75,88-90."""
     k = kernel_hwio.shape[0]
     assert k % 2 == 1 and kernel_hwio.shape[1] == k
-    w = kernel_hwio.permute(3, 2, 0, 1)
+    w = kernel_hwio.permute(3, 2, 0, 1).contiguous()       # (contiguous: torch-CPU's slow_conv2d backward refuses a strided grad_weight when C_out == 1)
     y = F.conv2d(_nchw(x), w, bias, stride=1, padding=(k - 1) // 2)
     y = _nhwc(y)
     return torch.relu(y) if relu else y

@@ -374,3 +374,20 @@ def test_stitch_and_recombine_bit_exact(lib):
     torch.cuda.synchronize()
     want = tiling_ref.recombine(passes)
     assert np.allclose(out.cpu().numpy(), want, rtol=0, atol=1e-5)     # fp32 fma contraction vs numpy: not bit-exact by design
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_conv_random_shapes(eng, seed):
+    """Seeded sweep over layer shapes the fixed cases do not list: channel counts around the 16 / 32 / 48 / 64 block and the 64-byte
+    K-chunk boundaries, image sizes around the 16x16 workgroup tile, every epilogue combination; both dtypes against the oracle."""
+    import random
+    rng = random.Random(1000 + seed)
+    k = rng.choice([1, 3, 3])
+    cin = rng.choice([1, 3, 6, 8, 16, 24, 25, 32, 40, 48, 56, 64, 72, 96, 104, 128, 136, 160, 192, 200])
+    cout = rng.choice([1, 3, 8, 16, 24, 25, 32, 40, 48, 64, 72, 80, 96, 112, 128, 144, 192])
+    H, W = rng.choice([1, 5, 15, 16, 17, 31, 33]), rng.choice([2, 7, 16, 18, 32, 35])
+    relu, in_relu, residual = rng.random() < 0.6, rng.random() < 0.3, rng.random() < 0.3
+    x_relu = (not in_relu) and rng.random() < 0.6
+    B = rng.choice([1, 2, 3])
+    for dtype in ("f32", "bf16"):
+        _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B=B)
