@@ -87,3 +87,40 @@ def _axis(extent, tile, overlap):
 def tile_plan(height, width, tile_size=128, tile_overlap_size=14) -> TilePlan:
     tile, overlap = effective_tile(height, width, tile_size, tile_overlap_size)
     return TilePlan(height, width, tile, overlap, _axis(height, tile, overlap), _axis(width, tile, overlap))
+
+
+def training_tile_grid(height, width, tiles_height_width):
+    """Training-side tiling of a rendered frame (TFRecordsCreator.py:125-133): non-overlapping tiles, remainders dropped.
+    Returns (rows, cols, [(y0, y1, x0, x1), ...]) in the reference's loop order (row-major; its "x" indexes height)."""
+    rows, cols = height // tiles_height_width, width // tiles_height_width
+    t = tiles_height_width
+    return rows, cols, [(i * t, (i + 1) * t, j * t, (j + 1) * t) for i in range(rows) for j in range(cols)]
+
+
+def source_index_tuples(number_of_sources_per_example, number_of_source_index_tuples, number_of_sources_per_target, rng=None):
+    """Which of an example's source renderings feed each training tuple (Training.py:879-913).
+
+    One source per target: as many full sweeps 0..S-1 as fit, the remainder drawn with `rng.randint(0, S-1)`; two sources per
+    target: distinct pairs by rejection.  `rng` defaults to Python's global `random` module, which is what the reference draws
+    from, so a seeded run reproduces its tuples draw for draw.  Returns (index_tuples, sorted unique indices)."""
+    import random as _random
+    rng = _random if rng is None else rng
+    S, n, per = number_of_sources_per_example, number_of_source_index_tuples, number_of_sources_per_target
+    if S < per:
+        raise Exception("The source index tuples contain unique indices. That is not possible if there are fewer source examples "
+                        "than indices per tuple.")
+    if per == 1:
+        tuples = [[i] for _ in range(n // S) for i in range(S)]
+        tuples += [[rng.randint(0, S - 1)] for _ in range(n % S)]
+    else:
+        if per > 2:
+            raise Exception("More than two source inputs are currently not supported!")
+        tuples = []
+        for _ in range(n):
+            picked = []
+            while len(picked) < per:
+                i = rng.randint(0, S - 1)
+                if i not in picked:
+                    picked.append(i)
+            tuples.append(picked)
+    return tuples, sorted({i for t in tuples for i in t})

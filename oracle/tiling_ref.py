@@ -1,66 +1,53 @@
-"""ORACLE (test infrastructure) -- literal restatement of the reference's inference tile plan,
-crop windows, stitch and recombination (TensorFlow/Prediction.py:259-311, :384-441, :443-481).
-Integer arithmetic: the product must match this BIT-EXACTLY.  Known answers: SURVEY.md App. C.
+"""ORACLE (test infrastructure) -- independent restatement of the reference's inference tile plan, crop windows, stitch
+and recombination (TensorFlow/Prediction.py:259-310, :384-441, :443-481), written per axis with numpy index vectors.
+Integer arithmetic: the product must match this BIT-EXACTLY.  It is itself pinned to tests/golden/tiling_golden.json, the
+outputs of the reference's own lines executed by tests/golden/make_tiling_golden.py (tests/test_tiling_golden.py); further
+known answers: SURVEY.md App. C.
 """
 import math
 
 import numpy as np
 
 
+def _effective(height, width, tile, overlap):
+    """Prediction.py:259-266: frames smaller than a tile shrink the tile and keep the overlap ratio."""
+    short = min(height, width)
+    if short < 16:
+        raise Exception('The image needs to have at least a side length of 16 pixels.')
+    if short < tile:
+        tile, overlap = short, int(short * (overlap / tile))
+    return tile, overlap
+
+
+def _axis_origins(extent, tile, overlap):
+    """Prediction.py:269-302 for one axis: count and lower bounds of the tiles."""
+    step = tile - 2 * overlap
+    count = math.ceil((extent - 2 * overlap - 2 * step) / step) + 2
+    lo = np.arange(count) * step
+    if count > 1:
+        lo[-1] = extent - tile          # the last tile is flush with the far border
+    return count, lo
+
+
 def plan(height, width, tile_size=128, tile_overlap_size=14):
     """Returns (tile_size, overlap, height_count, width_count, windows) where windows[h][w] =
-    (lower_height, upper_height, lower_width, upper_width) -- Prediction.py:259-311."""
-    smaller_side_length = min(height, width)
-    if smaller_side_length < 16:
-        raise Exception('The image needs to have at least a side length of 16 pixels.')
-    if smaller_side_length < tile_size:
-        ratio = tile_overlap_size / tile_size
-        tile_size = smaller_side_length
-        tile_overlap_size = int(tile_size * ratio)
-    iteration_delta = tile_size - (2 * tile_overlap_size)
-    width_count = width - (2 * tile_overlap_size) - (2 * iteration_delta)
-    width_count = width_count / iteration_delta
-    width_count = math.ceil(width_count) + 2
-    height_count = height - (2 * tile_overlap_size) - (2 * iteration_delta)
-    height_count = height_count / iteration_delta
-    height_count = math.ceil(height_count) + 2
-    windows = [[None for _ in range(width_count)] for _ in range(height_count)]
-    for height_index in range(height_count):
-        if height_index == 0:
-            lower_height, upper_height = 0, tile_size
-        elif height_index == height_count - 1:
-            upper_height = height
-            lower_height = upper_height - tile_size
-        else:
-            lower_height = height_index * iteration_delta
-            upper_height = lower_height + tile_size
-        for width_index in range(width_count):
-            if width_index == 0:
-                lower_width, upper_width = 0, tile_size
-            elif width_index == width_count - 1:
-                upper_width = width
-                lower_width = upper_width - tile_size
-            else:
-                lower_width = width_index * iteration_delta
-                upper_width = lower_width + tile_size
-            windows[height_index][width_index] = (lower_height, upper_height, lower_width, upper_width)
-    return tile_size, tile_overlap_size, height_count, width_count, windows
+    (lower_height, upper_height, lower_width, upper_width)."""
+    t, o = _effective(height, width, tile_size, tile_overlap_size)
+    hc, ys = _axis_origins(height, t, o)
+    wc, xs = _axis_origins(width, t, o)
+    windows = [[(int(y), int(y) + t, int(x), int(x) + t) for x in xs] for y in ys]
+    return t, o, hc, wc, windows
 
 
 def crop(index, count, extent, tile_size, tile_overlap_size):
-    """Valid window of tile `index` along one axis, in tile coordinates -- Prediction.py:396-425."""
-    lower, upper = 0, tile_size
-    if index != 0 and index != count - 1:
-        lower = tile_overlap_size
-        upper = upper - tile_overlap_size
-    elif index == 0 and index == count - 1:
-        pass
-    elif index == 0:
-        upper = upper - tile_overlap_size
-    else:
-        existing = tile_overlap_size + ((count - 1) * (tile_size - (2 * tile_overlap_size)))
-        remaining = extent - existing
-        lower = upper - remaining
+    """Valid window of tile `index` along one axis, in tile coordinates (Prediction.py:396-425): the first tile keeps its near
+    border, the last one supplies exactly what the tiles before it have not covered, interior tiles drop one overlap per side."""
+    first, last = index == 0, index == count - 1
+    lower = 0 if first else tile_overlap_size
+    upper = tile_size if last else tile_size - tile_overlap_size
+    if last and not first:
+        covered = tile_overlap_size + (count - 1) * (tile_size - 2 * tile_overlap_size)
+        lower = tile_size - (extent - covered)
     return lower, upper
 
 
