@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DD_LIB", os.path.join(_HERE, "libdd_hip.so"))   # DD_LIB: experiment builds (tools/)
 
-DD_F32, DD_BF16 = 0, 1
+DD_F32, DD_BF16, DD_F16 = 0, 1, 2
 IN_RELU, OUT_RELU, ACCUM, PIXSHUF, GATHER2X2 = 1, 2, 4, 8, 16
 MAX_FEATURES, MAX_COMBINED = 32, 8
 

@@ -12,6 +12,7 @@ MI355X-first differences from the reference's graph (results are the same, SURVE
 """
 
 import ctypes as C
+import json
 import math
 
 import torch
@@ -72,12 +73,14 @@ class FeaturePredictionTuple:
 
 class Architecture:
     def __init__(self, parsed_json, source_data_format="channels_last", data_format="channels_last",
-                 device="cuda", dtype="f32", seed=2):
+                 device="cuda", dtype="f32", seed=2, loss_scale=None):
         # `data_format` is accepted for drop-in compatibility; the MI355X path is NHWC-native, both values give the same results.
         if source_data_format != "channels_last":
             raise ValueError("features are exchanged channels_last (NHWC), as in the reference's callers")
         self.source_data_format, self.data_format = source_data_format, data_format
+        assert dtype in ("f32", "bf16", "f16"), dtype
         self.device, self.dtype, self.seed = torch.device(device), dtype, seed
+        self.loss_scale = loss_scale          # None: the storage type's default (program.Program)
         self.model_directory = parsed_json["model_directory"]
         self.number_of_sources_per_target = parsed_json["number_of_sources_per_target"]
         if self.number_of_sources_per_target != 1:
@@ -170,10 +173,12 @@ class Architecture:
     # ------------------------------------------------------------------ programs
     def program(self, B, H, W, training_json=None, architecture_json=None):
         """Static launch program for a (batch, tile size[, training settings]) configuration (cached)."""
-        key = (B, H, W, id(training_json) if training_json is not None else None)
+        # keyed on the CONTENT of the training settings: a mutated or re-created dict must not alias a stale program / loss descriptor
+        tkey = None if training_json is None else json.dumps(training_json, sort_keys=True, default=str)
+        key = (B, H, W, tkey)
         if key not in self._programs:
             from .program import Program
-            self._programs[key] = Program(self, B, H, W, training_json)
+            self._programs[key] = Program(self, B, H, W, None if training_json is None else json.loads(json.dumps(training_json)))
         return self._programs[key]
 
     def predict(self, features, mode=ModeKeys.PREDICT):

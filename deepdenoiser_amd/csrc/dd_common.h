@@ -44,6 +44,21 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
+// fp16 storage (DD_F16): a distinct 2-byte type so that templates can tell it from bf16 (a plain uint16_t).  Same MFMA rate as bf16
+// (v_mfma_f32_16x16x32_f16), 3 more mantissa bits, range +-65504: the inference type of BASELINE cfg-5 (inputs are log1p-standardized).
+struct f16_t { uint16_t v; };
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {      // round to nearest even (v_cvt_f16_f32 / v_cvt_pk_f16_f32)
+  const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void unpack_f16x2(uint32_t w, float& lo, float& hi) {
+  const f16x2_t v = __builtin_bit_cast(f16x2_t, w);
+  lo = (float)v[0]; hi = (float)v[1];
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int PER16 = 4;  // elements per 16 bytes
@@ -55,6 +70,15 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
   static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
 };
+template <> struct Elem<f16_t> {
+  static constexpr int PER16 = 8;
+  static __device__ __forceinline__ float to_f32(f16_t v) { return f16_to_f32(v.v); }
+  static __device__ __forceinline__ f16_t from_f32(float v) { return f16_t{__builtin_bit_cast(uint16_t, (_Float16)v)}; }
+};
+// two floats -> one packed pair of T (2-byte types)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
 
 // relu on a 16-byte vector of T
 template <typename T> __device__ __forceinline__ uint4 relu16(uint4 v);
@@ -70,6 +94,7 @@ template <> __device__ __forceinline__ uint4 relu16<bf16_t>(uint4 v) {
   v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
   return v;
 }
+template <> __device__ __forceinline__ uint4 relu16<f16_t>(uint4 v) { return relu16<bf16_t>(v); }   // sign bit 15 in both formats
 
 // 4 consecutive elements <-> float[4]
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
@@ -82,7 +107,17 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
   v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  unpack_f16x2(t.x, v[0], v[1]); unpack_f16x2(t.y, v[2], v[3]);
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float (&v)[4]) {
+  uint2 t;
+  t.x = pack_f16x2(v[0], v[1]);
+  t.y = pack_f16x2(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = t;
+}
 template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -108,7 +143,20 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   u.w = pack_bf16x2(v[6], v[7]);
   return u;
 }
-// keep the bf16 lanes of `v` whose mask lane is > 0 (ReLU-backward on packed data, no unpacking)
+// 8 elements of a 2-byte type T (one 16-byte vector) <-> float[8]
+template <typename T> __device__ __forceinline__ void unpack8t(uint4 u, float (&v)[8]);
+template <> __device__ __forceinline__ void unpack8t<bf16_t>(uint4 u, float (&v)[8]) { unpack8(u, v); }
+template <> __device__ __forceinline__ void unpack8t<f16_t>(uint4 u, float (&v)[8]) {
+  unpack_f16x2(u.x, v[0], v[1]); unpack_f16x2(u.y, v[2], v[3]); unpack_f16x2(u.z, v[4], v[5]); unpack_f16x2(u.w, v[6], v[7]);
+}
+template <typename T> __device__ __forceinline__ uint4 pack8t(const float (&v)[8]);
+template <> __device__ __forceinline__ uint4 pack8t<bf16_t>(const float (&v)[8]) { return pack8(v); }
+template <> __device__ __forceinline__ uint4 pack8t<f16_t>(const float (&v)[8]) {
+  uint4 u;
+  u.x = pack_f16x2(v[0], v[1]); u.y = pack_f16x2(v[2], v[3]); u.z = pack_f16x2(v[4], v[5]); u.w = pack_f16x2(v[6], v[7]);
+  return u;
+}
+// keep the bf16 / fp16 lanes of `v` whose mask lane is > 0 (sign bit clear and not zero: the same test in both formats) (ReLU-backward on packed data, no unpacking)
 __device__ __forceinline__ uint32_t mask_bf16x2(uint32_t v, uint32_t m) {
   const uint32_t lo = ((m & 0x8000u) == 0u && (m & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
   const uint32_t hi = ((m & 0x80000000u) == 0u && (m & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
@@ -142,6 +190,9 @@ template <typename T> __device__ __forceinline__ f32x4_t mma16(uint4 a, uint4 b,
 template <> __device__ __forceinline__ f32x4_t mma16<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+template <> __device__ __forceinline__ f32x4_t mma16<f16_t>(uint4 a, uint4 b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 template <> __device__ __forceinline__ f32x4_t mma16<float>(uint4 a, uint4 b, f32x4_t c) {
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
@@ -149,5 +200,14 @@ template <> __device__ __forceinline__ f32x4_t mma16<float>(uint4 a, uint4 b, f3
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   return c;
 }
+
+// Host-side dispatch on the storage dtype: `T` is float / bf16_t / f16_t inside the statement.
+#define DD_DISPATCH_DTYPE(dtype, T, ...)                     \
+  do {                                                       \
+    if ((dtype) == DD_F32) { using T = float; __VA_ARGS__; } \
+    else if ((dtype) == DD_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { using T = f16_t; __VA_ARGS__; }                   \
+  } while (0)
+static inline bool dd_dtype_ok(int dtype) { return dtype == DD_F32 || dtype == DD_BF16 || dtype == DD_F16; }
 
 static inline int dd_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -450,8 +450,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
               f32x4_t a = acc[j][r];
               if (out_relu && !R) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f); }
               uint2 pk;
-              pk.x = pack_bf16x2(a[0], a[1]);
-              pk.y = pack_bf16x2(a[2], a[3]);
+              pk.x = pack2<T>(a[0], a[1]);
+              pk.y = pack2<T>(a[2], a[3]);
               *reinterpret_cast<uint2*>(stage + lds_off(r * 16 + li, jj * 2 + (q >> 1)) + (q & 1) * 8) = pk;
             }
           const int n = n0 + jb * 16 + e_slot * 8;        // first of this lane's 8 channels
@@ -479,18 +479,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
               uint4 o4 = pv[k];
               if (R) {
                 float v[8], t[8];
-                unpack8(o4, v); unpack8(rv[k], t);
+                unpack8t<T>(o4, v); unpack8t<T>(rv[k], t);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[e] += t[e]; if (out_relu) v[e] = fmaxf(v[e], 0.f); }
-                o4 = pack8(v);
+                o4 = pack8t<T>(v);
               }
               if (M) o4 = mask_bf16x8(o4, mv[k]);
               if (accum) {
                 float v[8], t[8];
-                unpack8(o4, v); unpack8(av[k], t);
+                unpack8t<T>(o4, v); unpack8t<T>(av[k], t);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += t[e];
-                o4 = pack8(v);
+                o4 = pack8t<T>(v);
               }
               if (okv[k]) *reinterpret_cast<uint4*>(Y + pixv[k] * p.ldy + ch) = o4;
             }
@@ -551,9 +551,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 //                          with coalesced 16-byte vectors (+ mask / residual / accumulate), then write the patch to LDS.
 // A wave that stalls on memory cannot issue MFMAs, and HBM writes run at only ~3.2 TB/s (tools/ubench/mem_ubench.hip): with the
 // roles split, the SIMD's scheduler overlaps the I/O waves' stalls with the MFMA waves' matrix work.  Two barriers per unit.
-template <int NT, bool HALO>
+template <typename T, int NT, bool HALO>
 __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
-  using T = bf16_t;
+  static_assert(sizeof(T) == 2, "wave-specialised kernel: bf16 / fp16 storage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PH = PatchDim<HALO>::PH, PATCH_BYTES = PatchDim<HALO>::NPIX * DD_LDS_ROW;
   constexpr int STAGE_BYTES = DD_TILE * DD_TILE * DD_LDS_ROW;
@@ -637,8 +637,8 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
             f32x4_t a = acc[j][r];
             if (out_relu && !R) { a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f); }
             uint2 pk;
-            pk.x = pack_bf16x2(a[0], a[1]);
-            pk.y = pack_bf16x2(a[2], a[3]);
+            pk.x = pack2<T>(a[0], a[1]);
+            pk.y = pack2<T>(a[2], a[3]);
             *reinterpret_cast<uint2*>(stage + lds_off(r * 16 + li, j * 2 + (q >> 1)) + (q & 1) * 8) = pk;
           }
       }
@@ -733,18 +733,18 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
           uint4 o4 = pv[k];
           if (R) {
             float v[8], t[8];
-            unpack8(o4, v); unpack8(rv[k], t);
+            unpack8t<T>(o4, v); unpack8t<T>(rv[k], t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[e] += t[e]; if (out_relu) v[e] = fmaxf(v[e], 0.f); }
-            o4 = pack8(v);
+            o4 = pack8t<T>(v);
           }
           if (M) o4 = mask_bf16x8(o4, mv[k]);
           if (accum) {
             float v[8], t[8];
-            unpack8(o4, v); unpack8(av[k], t);
+            unpack8t<T>(o4, v); unpack8t<T>(av[k], t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += t[e];
-            o4 = pack8(v);
+            o4 = pack8t<T>(v);
           }
           if (okv[k]) *reinterpret_cast<uint4*>(Y + pixv[k] * p.ldy + ch) = o4;
         }
@@ -837,12 +837,12 @@ static size_t ws_weight_bytes(const ConvP& p, int nt) {
   return (size_t)p.taps * nslices * wb - ((p.kchunks & 1) ? (size_t)p.taps * (wb / 2) : 0);
 }
 
-template <int NT, bool HALO>
+template <typename T, int NT, bool HALO>
 int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
   const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, NT) + NT * 16 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<NT, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, NT, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   if (g_num_cus == 0) {
@@ -851,7 +851,7 @@ int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
     if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
   }
   long wgs = grid_size((long)g_num_cus, p);
-  hipLaunchKernelGGL((conv_igemm_ws_kernel<NT, HALO>), dim3((unsigned)wgs), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_ws_kernel<T, NT, HALO>), dim3((unsigned)wgs), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -878,7 +878,7 @@ int launch_nt(const ConvP& p, hipStream_t stream) {
   const bool resident = patch + (size_t)nslabs * NT * 16 * DD_LDS_ROW <= LDS_BUDGET;
   if constexpr (sizeof(T) == 2 && NT <= 4) {
     const size_t ws_lds = patch + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, NT) + NT * 16 * sizeof(float);
-    if (ws_enabled() && ws_lds <= 160 * 1024) return halo ? launch_ws<NT, true>(p, nslabs, stream) : launch_ws<NT, false>(p, nslabs, stream);
+    if (ws_enabled() && ws_lds <= 160 * 1024) return halo ? launch_ws<T, NT, true>(p, nslabs, stream) : launch_ws<T, NT, false>(p, nslabs, stream);
   }
   if (halo) return resident ? launch<T, NT, true, true>(p, nslabs, stream) : launch<T, NT, true, false>(p, nslabs, stream);
   return resident ? launch<T, NT, false, true>(p, nslabs, stream) : launch<T, NT, false, false>(p, nslabs, stream);
@@ -934,7 +934,7 @@ int dispatch(ConvP& p, hipStream_t stream) {
 
 extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->x && a->wp && a->y, "dd_conv_igemm: null pointer");
-  DD_REQUIRE(a->dtype == DD_F32 || a->dtype == DD_BF16, "dd_conv_igemm: bad dtype %d", a->dtype);
+  DD_REQUIRE(dd_dtype_ok(a->dtype), "dd_conv_igemm: bad dtype %d", a->dtype);
   const int esz = a->dtype == DD_F32 ? 4 : 2;
   const int per16 = 16 / esz;
   const bool gather = (a->flags & DD_GATHER2X2) != 0, pixshuf = (a->flags & DD_PIXSHUF) != 0;
@@ -959,5 +959,6 @@ extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   p.hin = gather ? 2 * a->H : a->H; p.win = gather ? 2 * a->W : a->W;
   p.hout = pixshuf ? 2 * a->H : a->H; p.wout = pixshuf ? 2 * a->W : a->W;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return a->dtype == DD_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
+  DD_DISPATCH_DTYPE(a->dtype, T, return dispatch<T>(p, s));
+  return DD_ERR_INVALID;
 }

@@ -121,9 +121,9 @@ __device__ __forceinline__ void bias_accumulate(float (&bsum)[8], const uint4 (&
     const int yx = pl.yx[it];
     const int py = yx >> 8, px = yx & 255;
     const bool use = yx >= 0 && (!interior_only || (py >= 1 && py <= DD_TILE && px >= 1 && px <= DD_TILE));
-    if (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
       float v[8];
-      unpack8(reg[it], v);
+      unpack8t<T>(reg[it], v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) bsum[e] += use ? v[e] : 0.f;
     } else {
@@ -156,9 +156,6 @@ __device__ __forceinline__ float frag_f32(const char* base, int py, int px, int 
   return *reinterpret_cast<const float*>(base + wg_off(py, px, pw, c >> 2) + (c & 3) * 4);
 }
 
-__device__ __forceinline__ f32x4_t mfma_bf16(uint4 a, uint4 b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
 
 template <typename T, int TAPS>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
@@ -273,7 +270,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NPW; ++j) acc[t][j] = mfma_bf16(ap[step % 3], bq[kst & 1][j], acc[t][j]);
+            for (int j = 0; j < NPW; ++j) acc[t][j] = mma16<T>(ap[step % 3], bq[kst & 1][j], acc[t][j]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -313,7 +310,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
               const uint4 bq = frag_tr_bf16(qtile, 2 * kst, DD_TILE, 0, ni0 + j, lane);
-              acc[t][j] = mfma_bf16(ap, bq, acc[t][j]);
+              acc[t][j] = mma16<T>(ap, bq, acc[t][j]);
             }
           }
         } else {
@@ -399,10 +396,10 @@ template <bool HALO> struct WgLds {
 //                         TAPS instead: wave = input tile (w & 1) x tap group (w >> 1) = taps {0,1,2} {3,4} {5,6} {7,8}.  Every gradient
 //                         element still has exactly one owner (no extra atomics), each wave runs 24 steps per tile instead of 72.
 //   MODE 2 (1x1):         as MODE 0 with one tap and no halo; the loop is 8 steps, fully unrolled.
-template <bool IN_RELU, int MODE>
+template <typename T, bool IN_RELU, int MODE>
 __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  using T = bf16_t;
+  static_assert(sizeof(T) == 2, "LDS-DMA weight gradient: bf16 / fp16 storage");
   constexpr bool HALO = MODE != 2;
   using LD = WgLds<HALO>;
   constexpr int KC = 64, NPW = 2, PW = LD::PW, WG_BUF = LD::BUF, WG_P_BYTES = LD::P_BYTES;
@@ -593,13 +590,13 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 #pragma unroll
         for (int jj = 0; jj < NPW; ++jj) {      // bq[k2 & 1][jj]: 8 pixels of channel lane&15 of n-tile nj + jj
           float f[8];
-          unpack8(bq[k2 & 1][jj], f);
+          unpack8t<T>(bq[k2 & 1][jj], f);
           bsum[jj] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) acc[i][j] = mfma_bf16(ap[g % RING], bq[k2 & 1][j], acc[i][j]);
+      for (int j = 0; j < NPW; ++j) acc[i][j] = mma16<T>(ap[g % RING], bq[k2 & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     };
     set_bases(ptile, qtile);
@@ -662,17 +659,18 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 #endif
 }
 
-template <bool IN_RELU, int MODE>
+template <typename T, bool IN_RELU, int MODE>
 static void launch_dma_mode(const WgradP& p, long blocks, hipStream_t stream) {
   const size_t lds = 2 * (size_t)WgLds<MODE != 2>::BUF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<IN_RELU, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<T, IN_RELU, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_dma_kernel<IN_RELU, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((wgrad_dma_kernel<T, IN_RELU, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
 }
 
+template <typename T>
 static int launch_dma(WgradP& p, hipStream_t stream) {
   // Work split.  A workgroup's time per tile is set by its busiest SIMD = the number of n-halves (2 x 16 output channels) its slice has,
   // plus a DMA/barrier floor: weight 3 for a full slice, 2 for a half one.  `target` workgroups in total (1 per CU).
@@ -698,9 +696,9 @@ static int launch_dma(WgradP& p, hipStream_t stream) {
   const long blocks = p.cstart[p.ncombo];
   const bool relu = (p.flags & DD_IN_RELU) != 0;
   const int mode = p.taps == 1 ? 2 : (p.m <= 32 && p.n <= 32) ? 1 : 0;
-  if (mode == 2) { if (relu) launch_dma_mode<true, 2>(p, blocks, stream); else launch_dma_mode<false, 2>(p, blocks, stream); }
-  else if (mode == 1) { if (relu) launch_dma_mode<true, 1>(p, blocks, stream); else launch_dma_mode<false, 1>(p, blocks, stream); }
-  else { if (relu) launch_dma_mode<true, 0>(p, blocks, stream); else launch_dma_mode<false, 0>(p, blocks, stream); }
+  if (mode == 2) { if (relu) launch_dma_mode<T, true, 2>(p, blocks, stream); else launch_dma_mode<T, false, 2>(p, blocks, stream); }
+  else if (mode == 1) { if (relu) launch_dma_mode<T, true, 1>(p, blocks, stream); else launch_dma_mode<T, false, 1>(p, blocks, stream); }
+  else { if (relu) launch_dma_mode<T, true, 0>(p, blocks, stream); else launch_dma_mode<T, false, 0>(p, blocks, stream); }
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -731,8 +729,10 @@ int dispatch(const WgradP& p, hipStream_t stream) {
   // (more than 32 channel-slice pairs -- > ~360 x 360 channels, Tiramisu transitions with wide filters -- do not fit the kernel's split table:
   //  those launches take the register-staged kernel below)
   if (sizeof(T) == 2 && (p.taps == 9 || p.taps == 1) && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && p.mslices * p.nslices <= 32 && dma_enabled()) {
-    WgradP q = p;
-    return launch_dma(q, stream);
+    if constexpr (sizeof(T) == 2) {
+      WgradP q = p;
+      return launch_dma<T>(q, stream);
+    }
   }
   switch (p.taps) {
     case 9: return launch<T, 9>(p, stream);
@@ -745,7 +745,7 @@ int dispatch(const WgradP& p, hipStream_t stream) {
 
 extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->p && a->q && a->out, "dd_conv_wgrad: null pointer");
-  DD_REQUIRE(a->dtype == DD_F32 || a->dtype == DD_BF16, "dd_conv_wgrad: bad dtype %d", a->dtype);
+  DD_REQUIRE(dd_dtype_ok(a->dtype), "dd_conv_wgrad: bad dtype %d", a->dtype);
   const int esz = a->dtype == DD_F32 ? 4 : 2, per16 = 16 / esz, kc = DD_LDS_ROW / esz;
   const bool gather = (a->flags & DD_GATHER2X2) != 0;
   DD_REQUIRE(a->taps == 9 || a->taps == 1 || (a->taps == 4 && gather), "dd_conv_wgrad: taps=%d unsupported", a->taps);
@@ -774,5 +774,6 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   if (ksplit > total_tiles) ksplit = (int)total_tiles;
   p.ksplit = ksplit;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return a->dtype == DD_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
+  DD_DISPATCH_DTYPE(a->dtype, T, return dispatch<T>(p, s));
+  return DD_ERR_INVALID;
 }

@@ -74,10 +74,7 @@ extern "C" int dd_pack_weights(const float* src, void* dst, int dtype, int taps,
   DD_REQUIRE(src && dst && taps > 0 && n > 0 && k > 0 && n_pad >= n && k_pad >= k, "dd_pack_weights: bad arguments");
   const long total = (long)taps * n_pad * k_pad;
   const unsigned g = min(grid_for(total), 2048u);
-  if (dtype == DD_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(g), dim3(256), 0, S(stream), src, (float*)dst, taps, n, k, n_pad, k_pad, s_tap, s_n, s_k, tap_flip);
-  else
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(g), dim3(256), 0, S(stream), src, (bf16_t*)dst, taps, n, k, n_pad, k_pad, s_tap, s_n, s_k, tap_flip);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(pack_kernel<T>, dim3(g), dim3(256), 0, S(stream), src, (T*)dst, taps, n, k, n_pad, k_pad, s_tap, s_n, s_k, tap_flip));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -100,8 +97,7 @@ __global__ void pack_batched_kernel(const dd_pack_desc* __restrict__ table) {
 extern "C" int dd_pack_weights_batched(const dd_pack_desc* table, int n_layers, int dtype, dd_stream stream) {
   DD_REQUIRE(table && n_layers > 0, "dd_pack_weights_batched: bad arguments");
   const dim3 g(64, (unsigned)n_layers);
-  if (dtype == DD_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, g, dim3(256), 0, S(stream), table);
-  else hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, g, dim3(256), 0, S(stream), table);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(pack_batched_kernel<T>, g, dim3(256), 0, S(stream), table));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -123,8 +119,7 @@ __global__ void colsum_kernel(const T* __restrict__ x, int ld, int c, long rows,
 extern "C" int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream) {
   DD_REQUIRE(x && out && c > 0 && rows > 0, "dd_colsum: bad arguments");
   dim3 g((unsigned)min((rows + 3) / 4, 1024L), (unsigned)((c + 63) / 64));
-  if (dtype == DD_F32) hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, S(stream), (const float*)x, ld, c, rows, out);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, dim3(256), 0, S(stream), (const bf16_t*)x, ld, c, rows, out);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, g, dim3(256), 0, S(stream), (const T*)x, ld, c, rows, out));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -144,7 +139,9 @@ template <typename T> struct Vec16 { static constexpr int N = Elem<T>::PER16; };
 template <typename T> __device__ __forceinline__ void vload(const T* p, float (&v)[Elem<T>::PER16]);
 template <> __device__ __forceinline__ void vload<float>(const float* p, float (&v)[4]) { load4<float>(p, v); }
 template <> __device__ __forceinline__ void vload<bf16_t>(const bf16_t* p, float (&v)[8]) { unpack8(*reinterpret_cast<const uint4*>(p), v); }
+template <> __device__ __forceinline__ void vload<f16_t>(const f16_t* p, float (&v)[8]) { unpack8t<f16_t>(*reinterpret_cast<const uint4*>(p), v); }
 template <typename T> __device__ __forceinline__ void vstore(T* p, const float (&v)[Elem<T>::PER16]);
+template <> __device__ __forceinline__ void vstore<f16_t>(f16_t* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack8t<f16_t>(v); }
 template <> __device__ __forceinline__ void vstore<float>(float* p, const float (&v)[4]) { store4<float>(p, v); }
 template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack8(v); }
 
@@ -193,15 +190,13 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restri
 extern "C" int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
                               int pool, int stride, int relu_mask, int dtype, dd_stream stream) {
   const int per16 = dtype == DD_F32 ? 4 : 8;
+  DD_REQUIRE(dd_dtype_ok(dtype), "bad dtype %d", dtype);
   DD_REQUIRE(x && y && idx && C % per16 == 0 && ldx % per16 == 0 && ldy % per16 == 0, "dd_maxpool_fwd: C, ld must be multiples of %d", per16);
   DD_REQUIRE(pool * pool < 255, "dd_maxpool_fwd: pool=%d too large", pool);
   int OH, OW, pby, pbx;
   same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
   const long total = (long)B * OH * OW * (C / per16);
-  if (dtype == DD_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)x, ldx, (float*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx, relu_mask);
-  else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx, relu_mask);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)x, ldx, (T*)y, ldy, idx, C, B, H, W, OH, OW, pool, stride, pby, pbx, relu_mask));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -260,14 +255,12 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uin
 extern "C" int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, const void* mask, int ldmask,
                               int C, int B, int H, int W, int pool, int stride, int accumulate, int dtype, dd_stream stream) {
   const int per16 = dtype == DD_F32 ? 4 : 8;
+  DD_REQUIRE(dd_dtype_ok(dtype), "bad dtype %d", dtype);
   DD_REQUIRE(dy && idx && dx && C % per16 == 0 && lddy % per16 == 0 && lddx % per16 == 0, "dd_maxpool_bwd: C, ld must be multiples of %d", per16);
   int OH, OW, pby, pbx;
   same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
   const long total = (long)B * H * W * (C / per16);
-  if (dtype == DD_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dy, lddy, idx, (float*)dx, lddx, (const float*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate);
-  else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)dy, lddy, idx, (bf16_t*)dx, lddx, (const bf16_t*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)dy, lddy, idx, (T*)dx, lddx, (const T*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -411,10 +404,10 @@ extern "C" int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n
                                int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(table && dst && n_tuples > 0 && n_entries > 0 && c_pad <= ld, "dd_gather_input: bad arguments");
   const int per16 = dtype == DD_F32 ? 4 : 8;
+  DD_REQUIRE(dd_dtype_ok(dtype), "bad dtype %d", dtype);
   DD_REQUIRE(c_pad % per16 == 0 && ld % per16 == 0, "dd_gather_input: c_pad=%d and ld=%d must be multiples of %d", c_pad, ld, per16);
   const long total = (long)n_tuples * B * H * W * (c_pad / per16);
-  if (dtype == DD_F32) hipLaunchKernelGGL(gather_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (float*)dst, ld, c_pad, B, (long)H * W);
-  else hipLaunchKernelGGL(gather_input_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (bf16_t*)dst, ld, c_pad, B, (long)H * W);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_input_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), table, n_tuples, n_entries, (T*)dst, ld, c_pad, B, (long)H * W));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -569,14 +562,14 @@ static int kpcn_dispatch(bool fwd, const float* src, int ldsrc, const void* logi
 extern "C" int dd_kpcn_fwd(const float* src, int ldsrc, const void* logits, int ldl, float* out, int ldo,
                            int B, int H, int W, int ksize, int dtype, dd_stream stream) {
   DD_REQUIRE(src && logits && out && ldl >= ksize * ksize, "dd_kpcn_fwd: bad arguments");
-  return dtype == DD_F32 ? kpcn_dispatch<float>(true, src, ldsrc, logits, ldl, nullptr, 0, out, ldo, 0, B, H, W, ksize, S(stream))
-                         : kpcn_dispatch<bf16_t>(true, src, ldsrc, logits, ldl, nullptr, 0, out, ldo, 0, B, H, W, ksize, S(stream));
+  DD_DISPATCH_DTYPE(dtype, T, return kpcn_dispatch<T>(true, src, ldsrc, logits, ldl, nullptr, 0, out, ldo, 0, B, H, W, ksize, S(stream)));
+  return DD_ERR_INVALID;
 }
 extern "C" int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
                            void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream) {
   DD_REQUIRE(src && logits && dout && dlogits && ldl >= ksize * ksize && dl_pad <= lddl, "dd_kpcn_bwd: bad arguments");
-  return dtype == DD_F32 ? kpcn_dispatch<float>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream))
-                         : kpcn_dispatch<bf16_t>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream));
+  DD_DISPATCH_DTYPE(dtype, T, return kpcn_dispatch<T>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream)));
+  return DD_ERR_INVALID;
 }
 
 // ------------------------------------------------------------------------------------------------ data augmentation
@@ -667,8 +660,7 @@ extern "C" int dd_compose_pack(const float* small, int lds, const float* fine, i
                                int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(small && fine && dst && H % 2 == 0 && W % 2 == 0 && c_pad >= 6 && c_pad <= ld, "dd_compose_pack: bad arguments");
   const long total = (long)B * H * W;
-  if (dtype == DD_F32) hipLaunchKernelGGL(compose_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (float*)dst, ld, c_pad, B, H, W);
-  else hipLaunchKernelGGL(compose_pack_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (bf16_t*)dst, ld, c_pad, B, H, W);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(compose_pack_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (T*)dst, ld, c_pad, B, H, W));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -709,8 +701,7 @@ extern "C" int dd_compose_blend_fwd(const float* small, int lds, const float* fi
                                     float* out, int ldo, int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(small && fine && wl && out && H % 2 == 0 && W % 2 == 0, "dd_compose_blend_fwd: bad arguments");
   const long total = (long)B * (H / 2) * (W / 2);
-  if (dtype == DD_F32) hipLaunchKernelGGL(compose_blend_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (const float*)wl, ldw, out, ldo, B, H, W);
-  else hipLaunchKernelGGL(compose_blend_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (const bf16_t*)wl, ldw, out, ldo, B, H, W);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(compose_blend_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), small, lds, fine, ldf, (const T*)wl, ldw, out, ldo, B, H, W));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -765,8 +756,7 @@ extern "C" int dd_compose_blend_bwd(const float* dout, int lddo, const float* sm
                                     void* dwl, int lddw, int dw_pad, int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(dout && small && fine && wl && dsmall && dfine && dwl && H % 2 == 0 && W % 2 == 0 && dw_pad <= lddw, "dd_compose_blend_bwd: bad arguments");
   const long total = (long)B * (H / 2) * (W / 2);
-  if (dtype == DD_F32) hipLaunchKernelGGL(compose_blend_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), dout, lddo, small, lds, fine, ldf, (const float*)wl, ldw, dsmall, ldds, accumulate_small, dfine, lddf, (float*)dwl, lddw, dw_pad, B, H, W);
-  else hipLaunchKernelGGL(compose_blend_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), dout, lddo, small, lds, fine, ldf, (const bf16_t*)wl, ldw, dsmall, ldds, accumulate_small, dfine, lddf, (bf16_t*)dwl, lddw, dw_pad, B, H, W);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(compose_blend_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), dout, lddo, small, lds, fine, ldf, (const T*)wl, ldw, dsmall, ldds, accumulate_small, dfine, lddf, (T*)dwl, lddw, dw_pad, B, H, W));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -800,8 +790,7 @@ extern "C" int dd_compose_unpack_bwd(const void* dnet, int ld, float* dsmall, in
                                      int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(dnet && dsmall && dfine && H % 2 == 0 && W % 2 == 0 && ld >= 6, "dd_compose_unpack_bwd: bad arguments");
   const long total = (long)B * (H / 2) * (W / 2);
-  if (dtype == DD_F32) hipLaunchKernelGGL(compose_unpack_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dnet, ld, dsmall, ldds, dfine, lddf, B, H, W);
-  else hipLaunchKernelGGL(compose_unpack_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)dnet, ld, dsmall, ldds, dfine, lddf, B, H, W);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(compose_unpack_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)dnet, ld, dsmall, ldds, dfine, lddf, B, H, W));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -1105,16 +1094,24 @@ extern "C" int dd_extract_tiles(const float* frame, int frame_h, int frame_w, in
   return DD_OK;
 }
 
+// Bit-exact with the numpy chain of Prediction.py:469-481: every np.multiply / np.add is one IEEE fp32 rounding, taken in the
+// reference's order (colour * (direct + indirect); then image = ((((d + g) + s) + t) + volume direct) + ...).  __fmul_rn / __fadd_rn
+// keep hipcc from contracting the products into FMAs, which would round once instead of twice.
 __global__ void recombine_kernel(const dd_recombine_desc d, long npix) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= npix * 3) return;
   float img = 0.f;
+  bool first = true;
   for (int k = 0; k < d.n_triples; ++k) {
-    const float v = d.color[k][i] * (d.direct[k][i] + d.indirect[k][i]);
+    const float v = __fmul_rn(d.color[k][i], __fadd_rn(d.direct[k][i], d.indirect[k][i]));
     if (d.combined[k]) d.combined[k][i] = v;
-    img += v;       // same left-to-right order as the np.add chain of Prediction.py:466-481
+    img = first ? v : __fadd_rn(img, v);
+    first = false;
   }
-  for (int j = 0; j < d.n_singles; ++j) img += d.single[j][i];
+  for (int j = 0; j < d.n_singles; ++j) {
+    img = first ? d.single[j][i] : __fadd_rn(img, d.single[j][i]);
+    first = false;
+  }
   d.image[i] = img;
 }
 extern "C" int dd_recombine(const dd_recombine_desc* desc, long npix, dd_stream stream) {
@@ -1156,8 +1153,7 @@ extern "C" int dd_masked_add(void* dst, int lddst, const void* src, int ldsrc, c
                              int accumulate, int dtype, dd_stream stream) {
   DD_REQUIRE(dst && src && C % 4 == 0 && lddst % 4 == 0 && ldsrc % 4 == 0 && (!mask || ldmask % 4 == 0), "dd_masked_add: C, ld must be multiples of 4");
   const long total = npix * (C / 4);
-  if (dtype == DD_F32) hipLaunchKernelGGL(masked_add_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (float*)dst, lddst, (const float*)src, ldsrc, (const float*)mask, ldmask, C, npix, accumulate);
-  else hipLaunchKernelGGL(masked_add_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (bf16_t*)dst, lddst, (const bf16_t*)src, ldsrc, (const bf16_t*)mask, ldmask, C, npix, accumulate);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(masked_add_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (T*)dst, lddst, (const T*)src, ldsrc, (const T*)mask, ldmask, C, npix, accumulate));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -1175,10 +1171,9 @@ extern "C" int dd_convert_channels(const void* src, int src_dtype, int ldsrc, vo
                                    long npix, dd_stream stream) {
   DD_REQUIRE(src && dst && nch > 0 && nch <= ldsrc && dst_pad <= lddst && npix > 0, "dd_convert_channels: bad arguments");
   const dim3 g(grid_for(npix)), b(256);
-  if (src_dtype == DD_F32 && dst_dtype == DD_F32) hipLaunchKernelGGL((convert_channels_kernel<float, float>), g, b, 0, S(stream), (const float*)src, ldsrc, (float*)dst, lddst, nch, dst_pad, npix);
-  else if (src_dtype == DD_F32) hipLaunchKernelGGL((convert_channels_kernel<float, bf16_t>), g, b, 0, S(stream), (const float*)src, ldsrc, (bf16_t*)dst, lddst, nch, dst_pad, npix);
-  else if (dst_dtype == DD_F32) hipLaunchKernelGGL((convert_channels_kernel<bf16_t, float>), g, b, 0, S(stream), (const bf16_t*)src, ldsrc, (float*)dst, lddst, nch, dst_pad, npix);
-  else hipLaunchKernelGGL((convert_channels_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)src, ldsrc, (bf16_t*)dst, lddst, nch, dst_pad, npix);
+  DD_REQUIRE(dd_dtype_ok(src_dtype) && dd_dtype_ok(dst_dtype), "dd_convert_channels: bad dtype");
+  DD_DISPATCH_DTYPE(src_dtype, TS, DD_DISPATCH_DTYPE(dst_dtype, TD,
+      hipLaunchKernelGGL((convert_channels_kernel<TS, TD>), g, b, 0, S(stream), (const TS*)src, ldsrc, (TD*)dst, lddst, nch, dst_pad, npix)));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -1201,8 +1196,7 @@ __global__ void zero_stuff_kernel(const T* __restrict__ x, int ldx, T* __restric
 extern "C" int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, int B, int H, int W, int dtype, dd_stream stream) {
   DD_REQUIRE(x && y && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "dd_zero_stuff: C, ld must be multiples of 4");
   const long total = (long)B * 4 * H * W * (C / 4);
-  if (dtype == DD_F32) hipLaunchKernelGGL(zero_stuff_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)x, ldx, (float*)y, ldy, C, B, H, W);
-  else hipLaunchKernelGGL(zero_stuff_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, C, B, H, W);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(zero_stuff_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)x, ldx, (T*)y, ldy, C, B, H, W));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
@@ -1241,8 +1235,7 @@ extern "C" int dd_zero_unstuff(const void* dy, int lddy, void* dx, int lddx, con
                                int accumulate, int dtype, dd_stream stream) {
   DD_REQUIRE(dy && dx && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "dd_zero_unstuff: C, ld must be multiples of 4");
   const long total = (long)B * H * W * (C / 4);
-  if (dtype == DD_F32) hipLaunchKernelGGL(zero_unstuff_kernel<float>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const float*)dy, lddy, (float*)dx, lddx, (const float*)mask, ldmask, C, B, H, W, accumulate);
-  else hipLaunchKernelGGL(zero_unstuff_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)mask, ldmask, C, B, H, W, accumulate);
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(zero_unstuff_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)dy, lddy, (T*)dx, lddx, (const T*)mask, ldmask, C, B, H, W, accumulate));
   DD_LAUNCH_CHECK();
   return DD_OK;
 }

@@ -7,7 +7,7 @@ closure that emits its backward launches, so `build_backward()` produces the rev
 lists of bound C calls on one HIP stream -- cheap to replay and capturable into a hipGraph.
 
 Conventions (see include/dd_hip.h): NHWC; tensor = (pointer, ld); activations are stored in the graph dtype
-('f32' parity path / 'bf16' throughput path) with channel counts padded to a multiple of 8 (pad channels are
+('f32' parity path / 'bf16' training throughput path / 'f16' inference path) with channel counts padded to a multiple of 8 (pad channels are
 always zero); ReLU backward is fused into the PRODUCER of a gradient (mask epilogues), so stored gradients are
 pre-activation gradients; multi-consumer tensors accumulate (first writer overwrites, later writers add).
 PyTorch provides device memory and streams only.
@@ -21,9 +21,12 @@ import torch
 
 from . import _lib as L
 
-_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16}
-_CODE = {"f32": L.DD_F32, "bf16": L.DD_BF16}
-_ESZ = {"f32": 4, "bf16": 2}
+# storage types of activations and packed weights: f32 = parity path (exact-f32 MFMA), bf16 = training throughput path, f16 = inference
+# path of BASELINE cfg-5 (fp16 MFMA at the bf16 rate, 3 more mantissa bits; range +-65504, so training in it needs the loss scale
+# of Program(loss_scale=...)); accumulation, losses, kernel-prediction softmax and blends are fp32 in every mode
+_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+_CODE = {"f32": L.DD_F32, "bf16": L.DD_BF16, "f16": L.DD_F16}
+_ESZ = {"f32": 4, "bf16": 2, "f16": 2}
 
 
 def round_up(v, m):
@@ -33,15 +36,14 @@ def round_up(v, m):
 class DT:
     """Device tensor handle: a channel-range view [ch0, ch0+C) of an NHWC torch buffer [B,H,W,ld]."""
 
-    zero_init_buffers = []   # gradient buffers that must be zeroed before every backward pass (registered on allocation)
-
     def __init__(self, buf, B, H, W, C, Cp, ch0, dtype, relu=False, requires_grad=False, gstate=None):
         self.buf, self.B, self.H, self.W, self.C, self.Cp, self.ch0, self.dtype = buf, B, H, W, C, Cp, ch0, dtype
         self.ld = buf.shape[-1]
         self.relu = relu                      # produced by a ReLU epilogue => incoming gradients get masked by (self > 0)
         self.requires_grad = requires_grad
         self.self_mask = False                # ReLU output whose consumers cannot mask (dense-concat ranges): the producer masks its own gradient in place
-        self.gstate = gstate if gstate is not None else {"buf": None, "written": False, "zero_init": False}
+        # "zero_list": the owning Graph's list of gradient buffers that are zeroed before every backward pass
+        self.gstate = gstate if gstate is not None else {"buf": None, "written": False, "zero_init": False, "zero_list": None}
 
     @property
     def ptr(self):
@@ -61,7 +63,7 @@ class DT:
             # zeros: pad channels of gradients must be zero; fully-written tensors overwrite anyway
             self.gstate["buf"] = torch.zeros_like(self.buf)
             if self.gstate["zero_init"]:
-                DT.zero_init_buffers.append(self.gstate["buf"])
+                self.gstate["zero_list"].append(self.gstate["buf"])
         return DT(self.gstate["buf"], self.B, self.H, self.W, self.C, self.Cp, self.ch0, self.dtype)
 
     @property
@@ -209,6 +211,7 @@ class Graph:
         self.pack_ops, self.fwd_ops, self.bwd_ops, self._tape = [], [], [], []
         self.layers = {}
         self.keep = []     # keeps auxiliary device buffers alive
+        self.zero_init_buffers = []     # gradient buffers with several partial-range writers: zeroed before every backward pass
         self.conv_records, self.wgrad_records = [], []
         self._pack_records = []
 
@@ -236,7 +239,9 @@ class Graph:
         ld = ld or Cp
         alloc = torch.zeros if zero else torch.empty
         buf = alloc((B, H, W, ld), dtype=_TORCH_DT[dtype], device=self.device)
-        return DT(buf, B, H, W, C, Cp, 0, dtype, relu, requires_grad)
+        t = DT(buf, B, H, W, C, Cp, 0, dtype, relu, requires_grad)
+        t.gstate["zero_list"] = self.zero_init_buffers
+        return t
 
     def layer(self, name, k, cin, cout, kind="conv"):
         if name not in self.layers:
@@ -324,7 +329,7 @@ class Graph:
         assert y.C == layer.cout
         ps = self.params
         flags = (L.OUT_RELU if relu else 0) | (L.IN_RELU if in_relu else 0)
-        do_split = (split_at is not None and self.dtype == "bf16" and layer.k == 3 and res is None and layer.cin > 128
+        do_split = (split_at is not None and self.dtype in ("bf16", "f16") and layer.k == 3 and res is None and layer.cin > 128
                     and 0 < split_at < layer.cin and split_at % 8 == 0 and max(split_at, layer.cin - split_at) <= 128
                     and os.environ.get("DD_CONV_SPLIT_CONCAT", "1") != "0")
         if do_split:

@@ -43,6 +43,12 @@ class Predictor:
         Bt = -(-plan.count // n_batches)          # balanced batches: 209 tiles at <= 64 per batch -> 4 x 53, not 3 x 64 + 17
         prog = self.arch.program(Bt, T, T)
         NF = prog.NF
+        # ONE_HOT_ENCODING: the reference's prediction input_fn adds the constant one-hot planes of every flag name to the source
+        # dictionary (Prediction.py:97-98 -> FeatureFlags.add_to_source_dictionary); they are written once here.  A caller may still
+        # pass 'feature_flag/<name>' frames, which predict_frame() tiles like any other input.
+        for name, buf in prog.flags_raw.items():
+            buf.zero_()
+            buf[..., self.arch.feature_flag_names.index(name)] = 1.0
         origins = plan.windows()                                                              # row-major (Prediction.py:380-382)
         grid = [(hi, wi) for hi in range(plan.rows.count) for wi in range(plan.cols.count)]
         chunks = []
@@ -80,7 +86,19 @@ class Predictor:
             fr = frame[Naming.source_feature_name(f.name, index=0)]
             if fr.dim() != 3 or fr.shape[2] < f.number_of_channels or tuple(fr.shape[:2]) != (H, W):
                 raise ValueError("%s: expected a [%d,%d,>=%d] frame, got %s" % (f.name, H, W, f.number_of_channels, tuple(fr.shape)))
+        flag_frames = {}
+        for name in prog.flags_raw:
+            key = Naming.feature_flags_name(name)
+            if key in features:
+                fr = torch.as_tensor(features[key], dtype=torch.float32).to(dev).contiguous()
+                if tuple(fr.shape) != (H, W, prog.flags_raw[name].shape[3]):
+                    raise ValueError("%s: expected a [%d,%d,%d] frame, got %s" % (key, H, W, prog.flags_raw[name].shape[3], tuple(fr.shape)))
+                flag_frames[name] = fr
         for oyx, tdev, n in chunks:
+            for name, fr in flag_frames.items():
+                raw = prog.flags_raw[name]
+                L.check(lib.dd_extract_tiles(fr.data_ptr(), H, W, fr.shape[2], fr.shape[2], raw.data_ptr(), T, raw.shape[3],
+                                             oyx.data_ptr(), oyx.shape[0], stream))
             for f in feats:                                              # halo tiles straight into the program's input buffers
                 fr = frame[Naming.source_feature_name(f.name, index=0)]
                 raw = prog.raw[f.name]

@@ -274,7 +274,29 @@ def _update_state(model_directory, name):
 
 
 # ---------------------------------------------------------------------------------------------------- the parameter arena
-def load_variables(arch, prefix, load_optimizer=True, strict=True, beta1=0.9):
+def _adam_step_from_powers(ck, beta1, beta2, global_step):
+    """Number of Adam updates t behind a checkpoint.  TF stores beta1_power = beta1 ** (t + 1) and beta2_power = beta2 ** (t + 1)
+    (float32): beta1_power resolves t exactly while it is a normal number (t < ~800 for 0.9), beta2_power up to ~8e4 steps;
+    beyond that (both underflowed or too flat to invert) the step is the Estimator's global_step, saved in the same file.  The step is
+    never silently reset: bias correction restarting on warm moments would cut the effective learning rate to ~0.3x."""
+    b1p = float(ck["beta1_power"].reshape(-1)[0])
+    b2p = float(ck["beta2_power"].reshape(-1)[0]) if "beta2_power" in ck else 0.0
+    tiny = float(np.finfo(np.float32).tiny)
+    if tiny * 1e3 < b1p < 1.0:
+        return max(int(round(np.log(b1p) / np.log(beta1))) - 1, 0)
+    if b1p >= 1.0:
+        raise CheckpointError("beta1_power = %r is not a power of beta1 = %r" % (b1p, beta1))
+    if tiny * 1e3 < b2p < 1.0:
+        t = int(round(np.log(b2p) / np.log(beta2))) - 1
+        if global_step is not None and abs(global_step - t) <= max(2, int(2e-3 * t)):
+            return int(global_step)      # float32 beta2_power resolves t to ~1e-3 relative; global_step is exact when it agrees
+        return max(t, 0)
+    if global_step is not None:
+        return int(global_step)
+    raise CheckpointError("beta1_power / beta2_power have underflowed and the checkpoint has no global_step: the Adam step is unknown")
+
+
+def load_variables(arch, prefix, load_optimizer=True, strict=True, beta1=0.9, beta2=0.999):
     """Copy a checkpoint into the architecture's parameter arena (built programs first: Architecture.program(...) or
     Predictor.prepare(...) create the variables).  With load_optimizer the Adam slots and step count are restored as well when the
     checkpoint has them.  strict: every variable of the model must be in the checkpoint with the same shape.
@@ -305,11 +327,10 @@ def load_variables(arch, prefix, load_optimizer=True, strict=True, beta1=0.9):
     if have_slots:
         ps.m.copy_(host["m"])
         ps.v.copy_(host["v"])
-        if "beta1_power" in ck:              # beta1_power = beta1 ** t after t updates (tf.train.AdamOptimizer._finish)
+        if "beta1_power" in ck:
             used.add("beta1_power")
             used.add("beta2_power")
-            b1p = float(ck["beta1_power"].reshape(-1)[0])
-            info["adam_step"] = int(round(np.log(b1p) / np.log(beta1))) if 0.0 < b1p < 1.0 else 0
+            info["adam_step"] = _adam_step_from_powers(ck, beta1, beta2, info["global_step"])
             arch.adam_step = info["adam_step"]
     info["unused"] = [k for k in ck if k not in used and k != "global_step"]
     return info
@@ -330,9 +351,11 @@ def save_variables(arch, model_directory, global_step, save_optimizer=True, beta
             tensors[p.name + "/Adam"] = m[sl].reshape(p.shape)
             tensors[p.name + "/Adam_1"] = v[sl].reshape(p.shape)
     if save_optimizer:
+        # tf.train.AdamOptimizer creates beta{1,2}_power with initial value beta and multiplies by beta in _finish(): after t
+        # updates the variables hold beta ** (t + 1) (a fresh model saves beta, never 1.0 -- TF computes 1 - beta1_power)
         t = getattr(arch, "adam_step", 0)
-        tensors["beta1_power"] = np.array(beta1 ** t, dtype=np.float32)
-        tensors["beta2_power"] = np.array(beta2 ** t, dtype=np.float32)
+        tensors["beta1_power"] = np.array(beta1 ** (t + 1), dtype=np.float32)
+        tensors["beta2_power"] = np.array(beta2 ** (t + 1), dtype=np.float32)
     name = "%s-%d" % (basename, global_step)
     prefix = os.path.join(model_directory, name)
     write_checkpoint(prefix, tensors)

@@ -68,9 +68,10 @@ def _open(path, mode):
     return gzip.open(path, mode) if path.endswith(".gz") else open(path, mode)
 
 
-def read_records(path, verify_payload_crc=False):
-    """Yield the raw records of a (.gz) TFRecord file.  The 12-byte length header is always CRC-checked; the payload CRC (pure-Python,
-    slow for multi-megabyte tiles) only on request."""
+def read_records(path, verify_payload_crc=True):
+    """Yield the raw records of a (.gz) TFRecord file.  Length header and payload are CRC-checked, as tf.data.TFRecordDataset does
+    (crc32c() hands payloads >= 4 KiB to the native dd_crc32c); verify_payload_crc=False skips the payload check when the native
+    library is unavailable and the pure-Python CRC of multi-megabyte tiles is too slow."""
     with _open(path, "rb") as f:
         while True:
             head = f.read(12)

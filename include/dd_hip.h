@@ -12,7 +12,8 @@
  *   - master weights / gradients / optimizer state are fp32 in TensorFlow variable layout:
  *     conv kernel HWIO [kh,kw,C_in,C_out]; transpose-conv kernel [kh,kw,C_out,C_in];
  *   - `dtype` selects the storage type of activations and packed weights: DD_F32 (parity path,
- *     exact-f32 MFMA) or DD_BF16 (throughput path, bf16 MFMA with fp32 accumulate);
+ *     exact-f32 MFMA), DD_BF16 (training throughput path, bf16 MFMA with fp32 accumulate) or
+ *     DD_F16 (inference path of BASELINE cfg-5: fp16 MFMA, fp32 accumulate; range +-65504);
  *   - return 0 on success, negative dd_status otherwise; dd_last_error() gives the message of the
  *     calling thread's last failure.  No exceptions cross the ABI.
  */
@@ -28,7 +29,7 @@ extern "C" {
 
 typedef void* dd_stream; /* hipStream_t */
 
-enum dd_dtype { DD_F32 = 0, DD_BF16 = 1 };
+enum dd_dtype { DD_F32 = 0, DD_BF16 = 1, DD_F16 = 2 };
 
 enum dd_status {
   DD_OK = 0,

@@ -1,7 +1,7 @@
 """Helpers shared by the -m gpu tests (HIP path vs the CPU oracle)."""
 import torch
 
-TOL = {"f32": 3e-5, "bf16": 2.5e-2}
+TOL = {"f32": 3e-5, "bf16": 2.5e-2, "f16": 3.5e-3}
 
 
 def rel_l2(a, b):
@@ -22,6 +22,8 @@ def representable(t, dtype):
     """Round values so that storing them in the graph dtype is lossless."""
     if dtype == "bf16":
         return t.to(torch.bfloat16).to(torch.float64)
+    if dtype == "f16":
+        return t.to(torch.float16).to(torch.float64)
     return t.to(torch.float32).to(torch.float64)
 
 

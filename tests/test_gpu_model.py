@@ -133,8 +133,10 @@ def test_training_step_parity_f32(case):
                 if float(go.abs().max()) == 0.0:
                     assert float(arch.params.grad(p).abs().max()) < 1e-6, n
                 else:
-                    # f32 vs f64 oracle: a handful of ReLU / sign(p-t) decisions flip at noise-level pre-activations => tolerance 5e-3, median reported
-                    errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
+                    # f32 vs f64 oracle: a handful of ReLU / sign(p-t) decisions flip at noise-level pre-activations.  Measured max over
+                    # the cases 3e-7 ... 2.2e-4; the 17-tuple example JSON (SMAPE on 17 passes + 4 combined + the image term over 2 x 32 x 32
+                    # pixels) measures 2.7e-3, so it alone keeps the wider gate
+                    errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3 if case == "example_json_single_embedding" else 5e-4))
             errs.sort()
             print("gradient rel-L2: median %.2e max %.2e" % (errs[len(errs) // 2], errs[-1]))
     # 3-step displacement.  Adam normalises every entry's step to ~lr, so noise-level gradient entries may move differently
@@ -166,7 +168,7 @@ def test_bf16_path_reports_its_tolerance():
     assert abs(float(loss) - float(loss_o)) < 3e-2 * abs(float(loss_o))
     errs = [rel_l2(arch.params.grad(p).cpu(), go) for p, go in zip(arch.params.params, grads_o) if float(go.norm()) > 0]
     print("bf16 gradient rel-L2: median %.3e max %.3e" % (sorted(errs)[len(errs) // 2], max(errs)))
-    assert sorted(errs)[len(errs) // 2] < 0.25
+    assert sorted(errs)[len(errs) // 2] < 0.14          # measured 9.0e-2 at 32x32 (3.5e-2 at 128x128: tests/test_gpu_round2.py)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -261,7 +263,7 @@ def test_variation_loss_terms_parity_f32(loss_difference):
     errs = []
     for p, n, go in zip(arch.params.params, names, grads_o):
         if float(go.abs().max()) > 0:
-            errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
+            errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 1e-3))     # measured max 2.1e-4
     print("variation-loss gradient rel-L2: median %.2e max %.2e" % (sorted(errs)[len(errs) // 2], max(errs)))
 
 
@@ -301,7 +303,7 @@ def test_masked_mean_loss_terms_parity_f32():
     errs = []
     for p, n, go in zip(arch.params.params, list(oracle.vs.vars.keys()), grads_o):
         if float(go.abs().max()) > 0:
-            errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 5e-3))
+            errs.append(check("grad " + n, arch.params.grad(p).cpu(), go, 1.5e-3))   # measured max 4.9e-4
     print("masked-loss gradient rel-L2: median %.2e max %.2e" % (sorted(errs)[len(errs) // 2], max(errs)))
 
 

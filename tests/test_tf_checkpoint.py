@@ -224,3 +224,41 @@ def test_load_variables_reports_missing_and_mismatched_variables(tmp_path):
     unbuilt = types.SimpleNamespace(params=ParamStore())
     with pytest.raises(RuntimeError, match="before load_variables"):
         TC.load_variables(unbuilt, prefix)
+
+
+@pytest.mark.parametrize("t", [0, 1, 41, 700, 5000, 60000, 300000])
+def test_adam_step_survives_the_checkpoint_at_any_length_of_run(tmp_path, t):
+    """tf.train.AdamOptimizer stores beta ** (t + 1) in float32: a fresh model saves beta (never 1.0, TF divides by 1 - beta1_power),
+    0.9 ** t underflows near t = 1000 and 0.999 ** t near t = 1e5 -- the step must come back exactly in every regime."""
+    a = _toy_arch(seed=3)
+    a.adam_step = t
+    prefix = TC.save_variables(a, str(tmp_path), global_step=t)
+    ck = TC.read_checkpoint(prefix)
+    assert float(ck["beta1_power"]) == float(np.float32(0.9 ** (t + 1))) and float(ck["beta2_power"]) == float(np.float32(0.999 ** (t + 1)))
+    if t == 0:
+        assert float(ck["beta1_power"]) == float(np.float32(0.9))
+    b = _toy_arch(seed=4)
+    info = TC.load_variables(b, prefix)
+    assert info["adam_step"] == t and b.adam_step == t
+
+
+def test_adam_step_of_a_tensorflow_written_checkpoint_is_not_off_by_one(tmp_path):
+    """After 7 updates TF holds beta1_power = 0.9 ** 8; global_step (counted by the Estimator) may lag or be absent."""
+    a = _toy_arch(seed=3)
+    prefix = TC.save_variables(a, str(tmp_path), global_step=7)
+    ck = dict(TC.read_checkpoint(prefix))
+    ck["beta1_power"] = np.array(0.9 ** 8, dtype=np.float32)
+    ck["beta2_power"] = np.array(0.999 ** 8, dtype=np.float32)
+    del ck["global_step"]
+    TC.write_checkpoint(prefix, ck)
+    assert TC.load_variables(_toy_arch(seed=1), prefix)["adam_step"] == 7
+    # both powers underflowed and no global_step: refuse instead of restarting the bias correction on warm moments
+    ck["beta1_power"] = np.array(0.0, dtype=np.float32)
+    ck["beta2_power"] = np.array(0.0, dtype=np.float32)
+    TC.write_checkpoint(prefix, ck)
+    with pytest.raises(TC.CheckpointError, match="Adam step is unknown"):
+        TC.load_variables(_toy_arch(seed=1), prefix)
+    # beta2_power alone (beta1_power underflowed, ~2000 steps)
+    ck["beta2_power"] = np.array(0.999 ** 2001, dtype=np.float32)
+    TC.write_checkpoint(prefix, ck)
+    assert abs(TC.load_variables(_toy_arch(seed=1), prefix)["adam_step"] - 2000) <= 2
