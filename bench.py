@@ -113,32 +113,69 @@ def cpu_baseline(aj, tj, H, W, budget_s=20.0):
                       "(oracle/; TensorFlow itself is not installable); thread count = best of a short sweep" % (n, B, H, W)}
 
 
-def inference_bench(args, device, rank, world):
-    """Full-frame inference (SURVEY 8d cfg-5): 1080x1920x32ch frame -> 209 halo tiles of 128^2 -> U-Net KPCN forward -> stitch.
-    A step = one frame; every rank denoises its own frames (replicas only, no collective).  MPix/s counts OUTPUT pixels."""
+def inference_frames(device, dtype, tile, batch, steps, warmup, seed):
+    """Times `steps` full 1080x1920 frames through Predictor on this rank; returns seconds."""
     from deepdenoiser_amd import configs
     from deepdenoiser_amd.architecture import Architecture
     from deepdenoiser_amd.naming import Naming
     from deepdenoiser_amd.prediction import Predictor
     H, W = 1080, 1920
-    arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype=args.dtype, seed=2)
-    pred = Predictor(arch, tile_size=args.tile, tile_overlap_size=14, tiles_per_batch=args.batch)
-    g = torch.Generator().manual_seed(7 + rank)
+    arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype=dtype, seed=2)
+    pred = Predictor(arch, tile_size=tile, tile_overlap_size=14, tiles_per_batch=batch)
+    g = torch.Generator().manual_seed(seed)
     frame = {Naming.source_feature_name(f.name, index=0): torch.randn(H, W, f.number_of_channels, generator=g).abs().to(device)
              for f in arch.feature_predictions + arch.auxiliary_features}
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         pred.predict_frame(frame)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         pred.predict_frame(frame)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0
+
+
+def inference_bench(args, device, rank, world):
+    """Full-frame inference (SURVEY 8d cfg-5): 1080x1920x32ch frame -> 209 halo tiles of 128^2 -> U-Net KPCN forward -> stitch.
+    A step = one frame; every rank denoises its own frames (replicas only, no collective).  MPix/s counts OUTPUT pixels."""
+    H, W = 1080, 1920
+    dt = inference_frames(device, args.dtype, args.tile, args.batch, args.steps, args.warmup, 7 + rank)
     if rank == 0:
         print(json.dumps({"metric": "inference MPix/s (1920x1080 frame, halo-tiled 128x128x32ch U-Net KPCN)", "value": world * args.steps * H * W / dt / 1e6,
                           "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": "BASELINE config 5: full-frame 1920x1080 inference, 209 halo tiles (overlap 14), tiles per batch %d" % args.batch}}))
+
+
+def extras(device, B, H, W):
+    """Secondary measurements carried by the default line so that the driver's record holds them too (BASELINE.json's metric also names
+    "inference MPix/s"; the 1e-4 parity gate applies to the f32 storage path, whose throughput is reported beside the bf16 one)."""
+    from deepdenoiser_amd import configs
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.training import Trainer
+    out = {}
+    steps = 10
+    dt = inference_frames(device, "f16", 128, 256, steps, 2, 7)
+    out["inference"] = {"metric": "inference MPix/s (1920x1080 frame, 209 halo tiles of 128x128x32ch, fp16 MFMA path, output pixels)",
+                        "value": steps * 1080 * 1920 / dt / 1e6, "unit": "MPix/s", "ms_per_frame": 1e3 * dt / steps, "dtype": "f16", "frames": steps}
+    torch.cuda.empty_cache()
+    Bf = min(B, 32)
+    arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype="f32", seed=2)
+    trainer = Trainer(arch, configs.bench_training(), Bf, H, W, world_size=1, use_graph=True)
+    feats, labels = synthetic_inputs(arch, Bf, H, W, device, seed=1000)
+    trainer.program.set_inputs(feats, labels)
+    for _ in range(3):
+        trainer.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 5
+    for _ in range(steps):
+        trainer.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["f32_path"] = {"metric": "train tiles/sec on the f32 storage path (exact-f32 MFMA; the path the 1e-4 parity gate applies to)",
+                       "value": Bf * steps / dt, "unit": "tiles/s", "ms_per_step": 1e3 * dt / steps, "tiles_per_step": Bf, "dtype": "f32"}
+    return out
 
 
 def augment_bench(args, device, rank, world):
@@ -178,7 +215,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="tile-passes per GPU per step (default 128); inference: tiles per batch "
                                                             "(default 256: the 209 tiles of a 1920x1080 frame go through in one batch)")
     ap.add_argument("--tile", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
+                    help="storage type (MFMA input type; accumulation is fp32): default bf16 for training, f16 for --mode inference (BASELINE config 5)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements of the default line (inference MPix/s, f32-path tiles/s)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "inference", "augment"],
@@ -190,6 +229,8 @@ def main():
 
     if args.batch is None:
         args.batch = 256 if args.mode == "inference" else 128
+    if args.dtype is None:
+        args.dtype = "f16" if args.mode == "inference" else "bf16"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,10 +300,10 @@ def main():
         fam = "conv_igemm"
         n, ms, flops = times[fam]
         achieved = flops / (ms * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
         # algorithmic HBM bytes of the same launches: every input and output element once, plus the output-shaped operands some launches
         # read (the ReLU mask of a dgrad, a residual, the gradient a launch accumulates into)
-        esz = 2 if args.dtype == "bf16" else 4
+        esz = 4 if args.dtype == "f32" else 2
         alg_bytes = sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r["extra_reads"])) * esz for r in trainer.program.g.conv_records)
         tr = measured_traffic(B, args.dtype)
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (fwd+dgrad implicit GEMM)" % args.dtype, "achieved": achieved, "peak": peak,
@@ -290,6 +331,8 @@ def main():
                        "example_json_tiles_per_s": world * B * args.steps / dt / 17.0, "inputs": "pinned host, copied every step" if args.host_inputs else "resident in HBM"},
             "roofline": roof,
         }
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(device, B, H, W)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(aj, tj, H, W)
         print(json.dumps(out))

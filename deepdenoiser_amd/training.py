@@ -84,12 +84,19 @@ class Trainer:
         self._graphs = None
         self.reducer = GradientReducer(arch.params.grads, world_size)
         self._warm = 0
+        # Masked means divide by the batch-GLOBAL mask count (Training.py:131-137).  With the batch sharded over ranks the per-rank counts
+        # are summed (one all-reduce of a few dozen floats per step, before the forward) and divided by the world size: the optimizer
+        # averages the ranks' gradients, so a rank's masked term must be  sum_rank(d * mask) * world / count_global.
+        self._reduce_masks = world_size > 1 and self.program.masked
+        if self._reduce_masks:
+            self.program.mask_reduce = self._mask_reduce
 
     # ------------------------------------------------------------------ segmentation by gradient readiness
     def _build_segments(self):
         prog, ps = self.program, self.arch.params
         g = prog.g
-        head = list(g.pack_ops) + list(g.fwd_ops)
+        # label-only launches (scaled targets, mask counts) join segment 0 unless the mask counts need their all-reduce first
+        head = list(g.pack_ops) + ([] if self._reduce_masks else list(prog.label_ops)) + list(g.fwd_ops)
         bwd = list(g.bwd_ops)
         last_writer = {}
         for i, op in enumerate(bwd):
@@ -114,11 +121,18 @@ class Trainer:
                 self._run_segment_eager(idx)
             self._graphs.append(gr)
 
+    def _mask_reduce(self, mask_sums):
+        import torch.distributed as dist
+        dist.all_reduce(mask_sums, op=dist.ReduceOp.SUM, group=self.reducer.group)
+        mask_sums.mul_(1.0 / self.world)
+
     # ------------------------------------------------------------------ one optimisation step
     def step(self):
         prog = self.program
         if self._segments is None:
             self._build_segments()
+        if self._reduce_masks:
+            prog.run_label_ops()              # eager, outside the hipGraphs: contains a collective
         if self.use_graph and self._graphs is None and self._warm >= 2:
             torch.cuda.synchronize()
             self._capture()
