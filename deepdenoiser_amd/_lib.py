@@ -21,7 +21,7 @@ SYMBOLS = (
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
-    "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles",
+    "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
 )
 
 
@@ -88,6 +88,25 @@ class StitchEntry(C.Structure):
                 ("crop_x1", C.c_int), ("dst_img", C.c_int), ("dst_y", C.c_int), ("dst_x", C.c_int)]
 
 
+class ComposeArgs(C.Structure):
+    _fields_ = [("small", C.c_void_p), ("ld_small", C.c_int), ("fine", C.c_void_p), ("ld_fine", C.c_int), ("out", C.c_void_p), ("ld_out", C.c_int),
+                ("w_in", C.c_void_p), ("b_in", C.c_void_p), ("w_res", C.c_void_p * 4), ("b_res", C.c_void_p * 4),
+                ("w_out", C.c_void_p), ("b_out", C.c_void_p),
+                ("save_netin", C.c_void_p), ("ld_netin", C.c_int), ("save_act", C.c_void_p * 5), ("ld_act", C.c_int * 5),
+                ("save_wl", C.c_void_p), ("ld_wl", C.c_int),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
+
+
+class ComposeBwdArgs(C.Structure):
+    _fields_ = [("small", C.c_void_p), ("ld_small", C.c_int), ("fine", C.c_void_p), ("ld_fine", C.c_int), ("dout", C.c_void_p), ("ld_dout", C.c_int),
+                ("act", C.c_void_p * 5), ("ld_act", C.c_int * 5), ("wl", C.c_void_p), ("ld_wl", C.c_int),
+                ("w_in", C.c_void_p), ("w_res", C.c_void_p * 4), ("w_out", C.c_void_p),
+                ("d_small", C.c_void_p), ("ld_dsmall", C.c_int), ("accumulate_small", C.c_int), ("d_fine", C.c_void_p), ("ld_dfine", C.c_int),
+                ("dw_in", C.c_void_p), ("db_in", C.c_void_p), ("dw_res", C.c_void_p * 4), ("db_res", C.c_void_p * 4),
+                ("dw_out", C.c_void_p), ("db_out", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
+
+
 class RecombineDesc(C.Structure):
     _fields_ = [("n_triples", C.c_int), ("color", C.c_void_p * 4), ("direct", C.c_void_p * 4), ("indirect", C.c_void_p * 4),
                 ("combined", C.c_void_p * 4), ("n_singles", C.c_int), ("single", C.c_void_p * 8), ("image", C.c_void_p)]
@@ -147,6 +166,8 @@ def load():
     lib.dd_loss_mask_sums.argtypes = [vp, i, i, i, vp, vp]
     lib.dd_crc32c.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.dd_extract_tiles.argtypes = [vp, i, i, i, i, vp, i, i, vp, i, vp]
+    lib.dd_compose_net_fwd.argtypes = [C.POINTER(ComposeArgs), vp]
+    lib.dd_compose_net_bwd.argtypes = [C.POINTER(ComposeBwdArgs), vp]
     _lib = lib
     return lib
 

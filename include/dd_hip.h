@@ -146,6 +146,43 @@ int dd_compose_blend_bwd(const float* dout, int lddo, const float* small, int ld
 int dd_compose_unpack_bwd(const void* dnet, int ld, float* dsmall, int ldds, float* dfine, int lddf,
                           int B, int H, int W, int dtype, dd_stream stream);
 
+/* ---- the whole compose net of one scale transition as ONE launch (MultiScalePrediction.compose_scales, MultiScalePrediction.py:36-93):
+ * out = fine - w * up(avg_pool2(fine)) + w * up(small),  w = sigmoid(relu(1x1(a3))),  a3 = two residual blocks over relu(1x1([up(small) | fine])).
+ * Weights are the fp32 master variables of scope 'reused_compose_scales' in TensorFlow layout (conv2d: [6][24]; conv2d_1..4: HWIO
+ * [3][3][24][24]; conv2d_5: [24][1]).  bf16 / fp16 storage only (f32 runs layer by layer through dd_conv_igemm).
+ * Training: the activations the layer-wise backward reads are stored when their pointers are non-NULL -- netin (the packed 6-channel
+ * input, ld >= 8), act[0..4] = a1, relu(r1), a2, relu(r3), a3 (24 channels, ld >= 24, ld % 8 == 0), wl = relu(1x1(a3)) (1 channel). */
+typedef struct {
+  const float* small; int ld_small;        /* [N, H/2, W/2, ld] fp32 */
+  const float* fine; int ld_fine;          /* [N, H, W, ld] fp32 */
+  float* out; int ld_out;                  /* [N, H, W, ld] fp32 */
+  const float* w_in; const float* b_in;
+  const float* w_res[4]; const float* b_res[4];
+  const float* w_out; const float* b_out;
+  void* save_netin; int ld_netin;
+  void* save_act[5]; int ld_act[5];
+  void* save_wl; int ld_wl;
+  int N, H, W, dtype;
+} dd_compose_args;
+int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream);
+
+/* Backward of dd_compose_net_fwd in ONE launch (TF autodiff of the same lines behind Training.py:701-702): d_fine is written, d_small is
+ * written or accumulated into, every weight / bias gradient is ADDED to its fp32 arena slot (TensorFlow variable layout) with one
+ * atomic per element per workgroup.  act[0..4], wl: the tensors the forward stored.  dout: dL/d(out), fp32. */
+typedef struct {
+  const float* small; int ld_small;
+  const float* fine; int ld_fine;
+  const float* dout; int ld_dout;
+  const void* act[5]; int ld_act[5];
+  const void* wl; int ld_wl;
+  const float* w_in; const float* w_res[4]; const float* w_out;
+  float* d_small; int ld_dsmall; int accumulate_small;
+  float* d_fine; int ld_dfine;
+  float* dw_in; float* db_in; float* dw_res[4]; float* db_res[4]; float* dw_out; float* db_out;
+  int N, H, W, dtype;
+} dd_compose_bwd_args;
+int dd_compose_net_bwd(const dd_compose_bwd_args* a, dd_stream stream);
+
 /* ---- inverse standardization (Architecture.py:48-55, Utilities.py:6-7), in place capable */
 int dd_invert_std_fwd(const float* x, float* y, long n, int use_log1p, float mean, float std, dd_stream stream);
 /* dx = dy * d(invert)/dx evaluated at the standardized value x */

@@ -244,3 +244,67 @@ def test_every_loss_difference_kind_f32(kind):
     # SMAPE's variation term divides by |dp| + |dt| + 0.01 of neighbour differences that are often near zero: f32-vs-f64 sign flips
     # there move single gradient entries (measured max 2.4e-3); the smooth kinds measure <= 9e-5
     _grad_errors(arch, oracle, grads_o, 5e-3 if kind == "SMAPE" else 5e-4, kind)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(3, 24, 40), (2, 64, 64), (1, 16, 16)])
+def test_fused_compose_net_matches_the_layerwise_path(dtype, shape, monkeypatch):
+    """csrc/dd_compose.hip (one forward and one backward launch per scale transition, 24-channel frames in LDS, 4-pixel halo recompute) against the
+    layer-by-layer lowering of the same storage type: every intermediate is rounded at the same points, so the two differ only in the
+    fp32 summation order inside the MFMAs -- predictions, loss and every gradient (the backward is the layer-wise one, reading the
+    activations the fused forward stored).  Ragged tiles (24x40 -> 12x20 at scale 1), images smaller than the 24x24 frame (16x16 -> 8x8)."""
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    B, H, W = shape
+    aj = configs.architecture(filters=(16, 16, 24), convs=1, flag_mode="NONE",
+                              combined={"Diffuse": {"Color": "Diffuse Color", "Direct": "Diffuse Direct", "Indirect": "Diffuse Indirect"}})
+    tj = configs.training(image_mean=0.0)
+    tj["combined_image_training_settings"]["statistics"]["track_mean"] = False
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(oracle, B, H, W)
+    preds_o = oracle.predict(feats)
+    dev, devl = {k: v.cuda() for k, v in feats.items()}, {k: v.cuda() for k, v in labels.items()}
+    runs = {}
+    for fuse in ("0", "1", "fwd_only"):
+        monkeypatch.setenv("DD_FUSE_COMPOSE", "0" if fuse == "0" else "1")
+        monkeypatch.setenv("DD_FUSE_COMPOSE_BWD", "1" if fuse == "1" else "0")
+        arch = Architecture(aj, device="cuda", dtype=dtype)
+        prog = arch.program(B, H, W, training_json=tj)
+        arch.params.load_list(list(oracle.vs.vars.values()))
+        tags = [getattr(op, "tag", "") for op in prog.g.fwd_ops]
+        assert ("compose_net" in tags) == (fuse != "0")
+        assert ("compose_net" in [getattr(op, "tag", "") for op in prog.g.bwd_ops]) == (fuse == "1")
+        infer = arch.program(B, H, W)                                  # inference program: the fused launch stores nothing
+        infer.set_inputs(dev)
+        infer.forward()
+        preds_inf = [{k: v.clone() for k, v in d.items()} for d in infer.prediction_dictionaries()]
+        loss = float(prog.train_step(dev, devl))
+        torch.cuda.synchronize()
+        preds = [{k: v.clone() for k, v in d.items()} for d in prog.prediction_dictionaries()]
+        runs[fuse] = (preds, preds_inf, loss, arch.params.grads.clone() / prog.loss_scale)
+    tol = {"bf16": 4e-3, "f16": 5e-4}[dtype]
+    (p0, i0, l0, g0), (p1, i1, l1, g1) = runs["0"], runs["1"]
+    for s in range(len(p0)):
+        for k in p0[s]:
+            assert rel_l2(p1[s][k], p0[s][k]) < tol, (s, k, rel_l2(p1[s][k], p0[s][k]))
+            assert torch.equal(i1[s][k], p1[s][k]), "training and inference programs disagree"
+            assert rel_l2(p1[s][k].cpu(), preds_o[s][k]) < {"bf16": 4e-2, "f16": 5e-3}[dtype]      # the storage type's own error (both paths)
+    assert abs(l1 - l0) <= tol * abs(l0)
+    assert rel_l2(g1, g0) < 10 * tol, rel_l2(g1, g0)
+    assert rel_l2(runs["fwd_only"][3], g0) < 10 * tol          # fused forward + layer-wise backward
+    # per-parameter view of the fused backward (the compose net's own six layers and everything upstream of it)
+    worst = 0.0
+    for q in arch.params.params:
+        a, b_ = g1[q.offset:q.offset + q.size], g0[q.offset:q.offset + q.size]
+        if float(b_.norm()) > 0:
+            worst = max(worst, rel_l2(a, b_))
+            assert rel_l2(a, b_) < 25 * tol, (q.name, rel_l2(a, b_))
+    # both against the f64 oracle: the fused path must be as close to the reference as the layer-wise one
+    _, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    go = torch.zeros_like(g0.cpu(), dtype=torch.float64)
+    for q, t in zip(arch.params.params, grads_o):
+        go[q.offset:q.offset + q.size] = t.reshape(-1)
+    e_fused, e_layer = rel_l2(g1.cpu(), go), rel_l2(g0.cpu(), go)
+    print("compose backward vs layer-wise, %s %s: worst per-parameter gradient rel-L2 %.2e; whole gradient vs the f64 oracle: fused %.3e, layer-wise %.3e"
+          % (dtype, shape, worst, e_fused, e_layer))
+    assert e_fused <= 1.3 * e_layer + 1e-4
