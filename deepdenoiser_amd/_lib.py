@@ -22,6 +22,7 @@ SYMBOLS = (
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
+    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd",
 )
 
 
@@ -107,6 +108,15 @@ class ComposeBwdArgs(C.Structure):
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
 
 
+class HeadArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("C", C.c_int), ("src", C.c_void_p), ("ldsrc", C.c_int),
+                ("wa", C.c_void_p), ("ba", C.c_void_p), ("wb", C.c_void_p), ("bb", C.c_void_p),
+                ("out", C.c_void_p), ("ld_out", C.c_int), ("dout", C.c_void_p), ("ld_dout", C.c_int),
+                ("dx", C.c_void_p), ("ld_dx", C.c_int), ("accumulate_dx", C.c_int),
+                ("dwa", C.c_void_p), ("dba", C.c_void_p), ("dwb", C.c_void_p), ("dbb", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int), ("dtype", C.c_int)]
+
+
 class RecombineDesc(C.Structure):
     _fields_ = [("n_triples", C.c_int), ("color", C.c_void_p * 4), ("direct", C.c_void_p * 4), ("indirect", C.c_void_p * 4),
                 ("combined", C.c_void_p * 4), ("n_singles", C.c_int), ("single", C.c_void_p * 8), ("image", C.c_void_p)]
@@ -168,6 +178,8 @@ def load():
     lib.dd_extract_tiles.argtypes = [vp, i, i, i, i, vp, i, i, vp, i, vp]
     lib.dd_compose_net_fwd.argtypes = [C.POINTER(ComposeArgs), vp]
     lib.dd_compose_net_bwd.argtypes = [C.POINTER(ComposeBwdArgs), vp]
+    lib.dd_kpcn_head_fwd.argtypes = [C.POINTER(HeadArgs), vp]
+    lib.dd_kpcn_head_bwd.argtypes = [C.POINTER(HeadArgs), vp]
     _lib = lib
     return lib
 

@@ -1,0 +1,603 @@
+// Fused kernel-prediction head on CDNA4: AdjustNumberOfChannels + KernelPredictor of one scale as ONE launch each way.
+//
+// Reference seams replaced (file:line in /root/reference): TensorFlow/Architecture.py:237-244 (AdjustNumberOfChannels.predict: 1x1 conv
+// C -> K + ReLU, 1x1 conv K -> K) and Architecture.py:260-289 -> KernelPrediction.py:11-63 (softmax over the K = k*k logits, symmetric
+// pad, per-pixel k x k filter of the 3-channel source), plus their TF-autodiff gradients (Training.py:701-702).
+//
+//   hid    = relu(Wa^T x + ba)                 K channels (25 for the 5x5 kernel)
+//   logits = Wb^T hid + bb                     K channels
+//   out_c  = sum_t softmax(logits)_t * src_sympad[p + t][c]
+//
+// The layer-by-layer path writes and re-reads the K-channel hid / logits tensors (and their gradients) through HBM: 3 launches forward and
+// 5 backward per scale for ~1 % of the flops.  Here a wave owns 16 pixels at a time; x is read ONCE, straight into MFMA B fragments
+// (NHWC: a lane's 8 channels of one pixel are 16 contiguous bytes), and everything else stays in registers:
+//   * a lane's hid values of the first GEMM (4 consecutive channels of each 16-channel tile of "its" pixel) ARE its k-group of the second
+//     GEMM -- the reduction index of a GEMM may be permuted freely as long as the weight operand uses the same permutation (`slot_ch`),
+//     so no shuffle or LDS round trip separates the two 1x1 layers, nor the two data-gradient GEMMs of the backward;
+//   * the softmax and the filter apply run on the four lanes that share a pixel (two xor-shuffles per reduction).
+// The backward recomputes hid / logits / softmax from x (two tiny GEMMs) instead of loading them, so the forward stores nothing.  Its weight
+// gradients need pixel-major operands: each wave parks 32 pixels of [hid | d logits | d hid | x] in a private LDS strip, reads them back
+// with ds_read_b64_tr_b16 and accumulates the gradient tiles in registers for the whole launch (bias gradients = an all-ones channel).
+#include "dd_common.h"
+
+namespace {
+
+struct HeadP {
+  const void* x; const float* src; const float* wa; const float* ba; const float* wb; const float* bb; float* out;
+  const float* dout; void* dx; float* dwa; float* dba; float* dwb; float* dbb;
+  int ldx, C, ldsrc, ldo, lddo, lddx, accumulate;
+  int N, H, W;
+  long npix;
+};
+
+template <int KS> struct HeadDim {
+  static constexpr int K = KS * KS, NT = (K + 15) / 16, P = (KS - 1) / 2;
+  static constexpr int ONES_POS = ((K / 16) << 2) + ((K % 16) >> 2) * 8 + (K & 3);   // slot position of channel K (the first unused one)
+};
+// hidden / logit channel held in slot e of k-group q: a lane's MFMA result registers in the order they come (tile e >> 2, element e & 3)
+__device__ __forceinline__ int slot_ch(int q, int e) { return (e >> 2) * 16 + q * 4 + (e & 3); }
+// ... and the inverse for a position pos = q * 8 + e of a 32-slot row
+__device__ __forceinline__ int pos_ch(int pos) { return slot_ch(pos >> 3, pos & 7); }
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_tr16_ptr;
+
+struct PixelAddr { int b, y, x; bool ok; };
+__device__ __forceinline__ PixelAddr pixel_of(long p, const HeadP& a) {
+  PixelAddr r;
+  r.ok = p < a.npix;
+  const long pc = r.ok ? p : a.npix - 1;
+  r.x = (int)(pc % a.W);
+  const long t = pc / a.W;
+  r.y = (int)(t % a.H);
+  r.b = (int)(t / a.H);
+  return r;
+}
+__device__ __forceinline__ int sym(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
+
+// The weight fragments of the two forward GEMMs, gathered once per wave from the fp32 master variables (TensorFlow layout [C][K], [K][K]).
+template <typename T, int KS, int NCH> struct FwdWeights {
+  uint4 a1[HeadDim<KS>::NT][NCH];   // GEMM 1: row n = j*16 + li, k = c*32 + q*8 + e          -> Wa[k][n]
+  uint4 a2[HeadDim<KS>::NT];        // GEMM 2: row n = j*16 + li, k-slot (q, e) = channel slot_ch -> Wb[slot_ch][n]
+  float b1[HeadDim<KS>::NT][4], b2[HeadDim<KS>::NT][4];      // biases of this lane's result channels j*16 + q*4 + e
+};
+// The fp32 master weights, staged ONCE per workgroup into LDS with coalesced loads: [Wa (C x K) | Wb (K x K) | ba | bb].  A lane's fragment
+// elements are K floats apart (100 bytes for K = 25): gathered straight from global memory every wave-instruction touches ~50 cache lines,
+// and with every wave of the launch doing it at once that alone was ~70 us per launch; from LDS the odd stride is conflict-free.
+struct HeadW { const float* wa; const float* wb; const float* ba; const float* bb; int C; };
+template <int KS>
+__device__ __forceinline__ HeadW stage_head_weights(float* lds, const HeadP& a, int nthreads) {
+  constexpr int K = HeadDim<KS>::K;
+  const int nwa = a.C * K;
+  for (int i = threadIdx.x; i < nwa; i += nthreads) lds[i] = a.wa[i];
+  for (int i = threadIdx.x; i < K * K; i += nthreads) lds[nwa + i] = a.wb[i];
+  for (int i = threadIdx.x; i < K; i += nthreads) { lds[nwa + K * K + i] = a.ba[i]; lds[nwa + K * K + K + i] = a.bb[i]; }
+  __syncthreads();
+  HeadW h;
+  h.wa = lds; h.wb = lds + nwa; h.ba = lds + nwa + K * K; h.bb = h.ba + K; h.C = a.C;
+  return h;
+}
+
+template <typename T, int KS, int NCH>
+__device__ __forceinline__ void load_fwd_weights(FwdWeights<T, KS, NCH>& w, const HeadW& a, int li, int q) {
+  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 16 + li;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                      // (unconditional loads from clamped indices, zeroed afterwards: see head_fwd_kernel)
+        const int k = c * 32 + q * 8 + e;
+        const bool ok = n < K && k < a.C;
+        const float t = a.wa[ok ? k * K + n : 0];
+        v[e] = ok ? t : 0.f;
+      }
+      w.a1[j][c] = pack8t<T>(v);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = slot_ch(q, e);
+      const bool ok = n < K && (e >> 2) < NT && ch < K;
+      const float t = a.wb[ok ? ch * K + n : 0];
+      v[e] = ok ? t : 0.f;
+    }
+    w.a2[j] = pack8t<T>(v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = j * 16 + q * 4 + e;
+      const float t1 = a.ba[ch < K ? ch : 0], t2 = a.bb[ch < K ? ch : 0];
+      w.b1[j][e] = ch < K ? t1 : 0.f;
+      w.b2[j][e] = ch < K ? t2 : 0.f;
+    }
+  }
+}
+
+// x fragments of one pixel (B operand of GEMM 1): 8 channels = 16 bytes per k-group; zero beyond C
+template <typename T, int NCH>
+__device__ __forceinline__ void load_x(uint4 (&xf)[NCH], const HeadP& a, long pix, int q) {
+  const T* px = reinterpret_cast<const T*>(a.x) + pix * a.ldx;
+  const T* zero = reinterpret_cast<const T*>(&dd_zero16_v);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = c * 32 + q * 8;
+    xf[c] = *reinterpret_cast<const uint4*>(ch < a.C ? px + ch : zero);
+  }
+}
+
+// hid (as the k-group of GEMM 2, in the storage type) and the logits of this lane's channels, both rounded as the layer-wise path stores them
+// a1_lds != nullptr: the GEMM-1 weight fragments are read from a fragment-ready LDS image ([j][c][lane] x 16 bytes) instead of registers
+// (the backward kernel keeps up to 22 gradient tiles in registers and has none to spare for them)
+template <typename T, int KS, int NCH>
+__device__ __forceinline__ void forward_gemms(const FwdWeights<T, KS, NCH>& w, const uint4 (&xf)[NCH], uint4& hid, float (&lg)[HeadDim<KS>::NT][4],
+                                              const uint4* a1_lds = nullptr) {
+  constexpr int NT = HeadDim<KS>::NT;
+  float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    f32x4_t acc = {w.b1[j][0], w.b1[j][1], w.b1[j][2], w.b1[j][3]};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc = mma16<T>(a1_lds ? a1_lds[(j * NCH + c) * 64] : w.a1[j][c], xf[c], acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[j * 4 + e] = fmaxf(acc[e], 0.f);
+  }
+  hid = pack8t<T>(h);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    f32x4_t acc = {w.b2[j][0], w.b2[j][1], w.b2[j][2], w.b2[j][3]};
+    acc = mma16<T>(w.a2[j], hid, acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lg[j][e] = Elem<T>::to_f32(Elem<T>::from_f32(acc[e]));
+  }
+}
+
+// softmax over the K logits of a pixel, spread over the four lanes (q) that share it: p[j][e] for channel j*16 + q*4 + e (0 for channels >= K)
+template <int KS>
+__device__ __forceinline__ void softmax4(float (&lg)[HeadDim<KS>::NT][4], int q) {
+  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (j * 16 + q * 4 + e < K) mx = fmaxf(mx, lg[j][e]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lg[j][e] = j * 16 + q * 4 + e < K ? __expf(lg[j][e] - mx) : 0.f;
+      sum += lg[j][e];
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lg[j][e] *= inv;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------ forward
+template <typename T, int KS, int NCH>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadP a) {
+  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, P = HeadDim<KS>::P;
+  const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  __shared__ float s_w[128 * HeadDim<KS>::K + HeadDim<KS>::K * HeadDim<KS>::K + 2 * HeadDim<KS>::K];
+  const HeadW hw = stage_head_weights<KS>(s_w, a, 256);
+  FwdWeights<T, KS, NCH> w;
+  load_fwd_weights<T, KS, NCH>(w, hw, li, q);
+  const long ngroups = (a.npix + 15) >> 4;
+  for (long grp = wave; grp < ngroups; grp += nwaves) {
+    const PixelAddr pa = pixel_of(grp * 16 + li, a);
+    const long pix = ((long)pa.b * a.H + pa.y) * a.W + pa.x;
+    uint4 xf[NCH];
+    load_x<T, NCH>(xf, a, pix, q);
+    uint4 hid;
+    float p[NT][4];
+    forward_gemms<T, KS, NCH>(w, xf, hid, p);
+    softmax4<KS>(p, q);
+    const float* img = a.src + (long)pa.b * a.H * a.W * a.ldsrc;
+    // the taps this lane's channels stand for.  Every load is unconditional (channels >= K re-read tap 0 with weight 0): a branch per tap
+    // would put a full memory round trip behind each of them instead of one behind all
+    float sv[NT][4][3];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t0 = j * 16 + q * 4 + e, t = t0 < K ? t0 : 0;
+        const int ty = t / KS, tx = t - ty * KS;
+        const float* s = img + ((long)sym(pa.y + ty - P, a.H) * a.W + sym(pa.x + tx - P, a.W)) * a.ldsrc;
+        sv[j][e][0] = s[0]; sv[j][e][1] = s[1]; sv[j][e][2] = s[2];
+      }
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o0 += p[j][e] * sv[j][e][0]; o1 += p[j][e] * sv[j][e][1]; o2 += p[j][e] * sv[j][e][2]; }
+    o0 += __shfl_xor(o0, 16); o0 += __shfl_xor(o0, 32);
+    o1 += __shfl_xor(o1, 16); o1 += __shfl_xor(o1, 32);
+    o2 += __shfl_xor(o2, 16); o2 += __shfl_xor(o2, 32);
+    if (pa.ok && q < 3) a.out[pix * a.ldo + q] = q == 0 ? o0 : (q == 1 ? o1 : o2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------ backward
+// transposed MFMA fragment from a wave-private [32 pixels][row bytes] strip: channel tile `ctile` (16 channels = 32 bytes), the 8 pixels of k-group g
+__device__ __forceinline__ uint4 strip_frag_tr(const char* strip, int row_bytes, int ctile, int lane) {
+  const int t16 = lane & 15, g = lane >> 4;
+  const char* a0 = strip + (g * 8 + (t16 >> 2)) * row_bytes + ctile * 32 + (t16 & 3) * 8;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr16_ptr)(a0));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr16_ptr)(a0 + 4 * row_bytes));
+  uint4 r;
+  r.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+  r.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+  r.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+  r.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+  return r;
+}
+
+constexpr int BWD_WAVES = 8;      // one persistent workgroup per CU, 2 waves per SIMD (a wave's 32-pixel step is a chain of memory round trips)
+template <typename T, int KS, int NCH>
+__global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a) {
+  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, P = HeadDim<KS>::P, ONES = HeadDim<KS>::ONES_POS;
+  constexpr int CT = NCH * 2;                          // 16-channel tiles of x
+  constexpr int XROW = NCH * 64, STRIP = 32 * (3 * 64 + XROW);
+  constexpr int NA1 = HeadDim<KS>::NT * NCH;           // fragment-ready weight images behind the strips: GEMM 1 (NA1 KiB) and GEMM 4 (CT KiB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+  char* s_hid = smem + wv * STRIP;                     // [32 px][32 slots] hid (slot order, position ONES := 1)
+  char* s_dl = s_hid + 32 * 64;                        // [32 px][32 slots] d logits
+  char* s_dh = s_dl + 32 * 64;                         // [32 px][32 slots] d hid (pre-activation)
+  char* s_x = s_dh + 32 * 64;                          // [32 px][NCH * 32 channels] x
+  const long wave = (long)blockIdx.x * BWD_WAVES + wv, nwaves = (long)gridDim.x * BWD_WAVES;
+
+  const HeadW hw = stage_head_weights<KS>(reinterpret_cast<float*>(smem), a, BWD_WAVES * 64);      // (the strips are not in use yet)
+  FwdWeights<T, KS, NCH> w;
+  load_fwd_weights<T, KS, NCH>(w, hw, li, q);
+  // data-gradient operands: GEMM 3  d hid[m] = sum_n Wb[m][n] dl[n]  (row m = j*16 + li, k-slot -> n = slot_ch)
+  //                         GEMM 4  d x[c]   = sum_m Wa[c][m] dh[m]  (row c = ct*16 + li, k-slot -> m = slot_ch)
+  uint4 a3[NT], a4[CT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int m = j * 16 + li;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = slot_ch(q, e);
+      const bool ok = m < K && (e >> 2) < NT && n < K;
+      const float t = hw.wb[ok ? m * K + n : 0];
+      v[e] = ok ? t : 0.f;
+    }
+    a3[j] = pack8t<T>(v);
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = ct * 16 + li;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int mm = slot_ch(q, e);
+      const bool ok = c < a.C && (e >> 2) < NT && mm < K;
+      const float t = hw.wa[ok ? c * K + mm : 0];
+      v[e] = ok ? t : 0.f;
+    }
+    a4[ct] = pack8t<T>(v);
+  }
+  uint4* s_a1 = reinterpret_cast<uint4*>(smem + BWD_WAVES * STRIP) + lane;
+  uint4* s_a4 = s_a1 + NA1 * 64;
+  if (wv == 0) {                                       // the fragments depend on the lane only: one wave publishes them for all
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) s_a1[(j * NCH + c) * 64] = w.a1[j][c];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) s_a4[ct * 64] = a4[ct];
+  }
+  __syncthreads();                                     // every wave has its fragments: the staged weights give way to the strips
+  // weight-gradient tiles, kept for the whole launch (rows / columns of the K-sized dimensions are slot POSITIONS, mapped back at the end)
+  // (a 32-slot row always spans NPT = 2 position tiles: with one channel tile (3x3 kernels) the valid slots e < 4 of all four k-groups
+  //  still land in both halves of the row)
+  constexpr int NPT = 2;
+  f32x4_t g_wb[NPT][NPT], g_ba[NPT], g_wa[CT][NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    g_ba[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) g_wb[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) g_wa[ct][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#ifdef HB_EXP_NO_LOOP
+  const long nsteps = 0;
+#else
+  const long nsteps = (a.npix + 31) >> 5;
+#endif
+  // x of the NEXT 16-pixel subgroup is requested one subgroup ahead (the HBM round trip); everything else a subgroup reads (d out, source
+  // taps, ReLU masks, the gradient it accumulates into) is requested together at its top: one exposed round trip per subgroup, not five.
+  uint4 xnext[NCH];
+  {
+    const PixelAddr p0 = pixel_of(wave * 32 + li, a);
+    load_x<T, NCH>(xnext, a, ((long)p0.b * a.H + p0.y) * a.W + p0.x, q);
+  }
+  for (long step = wave; step < nsteps; step += nwaves) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const PixelAddr pa = pixel_of(step * 32 + s * 16 + li, a);
+      const long pix = ((long)pa.b * a.H + pa.y) * a.W + pa.x;
+      uint4 xf[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xf[c] = xnext[c];
+      {
+        const long nstep = s == 0 ? step : step + nwaves;
+        const PixelAddr pn = pixel_of(nstep * 32 + (1 - s) * 16 + li, a);          // (clamped to the last pixel past the end)
+        load_x<T, NCH>(xnext, a, ((long)pn.b * a.H + pn.y) * a.W + pn.x, q);
+      }
+      // (every load below is unconditional: pixels past the end were clamped by pixel_of and are masked by `okf`, channels >= K re-read
+      //  tap 0 and carry p = 0 -- see the forward kernel)
+      const float okf = pa.ok ? 1.f : 0.f;
+      const float g0 = okf * a.dout[pix * a.lddo], g1 = okf * a.dout[pix * a.lddo + 1], g2 = okf * a.dout[pix * a.lddo + 2];
+      const float* img = a.src + (long)pa.b * a.H * a.W * a.ldsrc;
+      float sv[NT][4][3];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int t0 = j * 16 + q * 4 + e, t = t0 < K ? t0 : 0;
+          const int ty = t / KS, tx = t - ty * KS;
+          const float* sp = img + ((long)sym(pa.y + ty - P, a.H) * a.W + sym(pa.x + tx - P, a.W)) * a.ldsrc;
+#ifdef HB_EXP_NO_TAPS
+          sv[j][e][0] = (float)t; sv[j][e][1] = 1.f; sv[j][e][2] = (float)(size_t)sp * 0.f;
+#else
+          sv[j][e][0] = sp[0]; sv[j][e][1] = sp[1]; sv[j][e][2] = sp[2];
+#endif
+        }
+      T* dxp = reinterpret_cast<T*>(a.dx) + pix * a.lddx;
+      const T* xp = reinterpret_cast<const T*>(a.x) + pix * a.ldx;
+      uint2 xm[CT], old[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + q * 4, cc = c < a.C ? c : 0;
+#ifdef HB_EXP_NO_DX
+        xm[ct] = uint2{(unsigned)cc, 0u}; old[ct] = uint2{0u, 0u};
+#else
+        xm[ct] = *reinterpret_cast<const uint2*>(xp + cc);
+        old[ct] = a.accumulate ? *reinterpret_cast<const uint2*>(dxp + cc) : uint2{0u, 0u};
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);               // all of the above is in flight before the first MFMA waits for x
+
+      uint4 hid;
+      float p[NT][4];
+      forward_gemms<T, KS, NCH>(w, xf, hid, p, s_a1);
+      softmax4<KS>(p, q);
+      // d logits of this lane's channels: p_t (dp_t - sum_u p_u dp_u),  dp_t = d out . src[tap t]
+      float dp[NT][4], dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dp[j][e] = g0 * sv[j][e][0] + g1 * sv[j][e][1] + g2 * sv[j][e][2];
+          dot += p[j][e] * dp[j][e];
+        }
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      float dlv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dlv[j * 4 + e] = p[j][e] * (dp[j][e] - dot);
+      const uint4 dl = pack8t<T>(dlv);                 // stored in the storage type by the layer-wise path: round here too
+      // GEMM 3 + ReLU mask of hid -> d hid (pre-activation), as the k-group of GEMM 4
+      float hv[8], dhv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      unpack8t<T>(hid, hv);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma16<T>(a3[j], dl, acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dhv[j * 4 + e] = hv[j * 4 + e] > 0.f ? acc[e] : 0.f;
+      }
+      const uint4 dh = pack8t<T>(dhv);
+      // GEMM 4 -> d x, masked by x > 0 (x is a ReLU output of the backbone), optionally accumulated into an existing gradient
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + q * 4;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma16<T>(s_a4[ct * 64], dh, acc);
+        float m8[8], o8[8], v[4];
+        unpack8t<T>(uint4{xm[ct].x, xm[ct].y, 0u, 0u}, m8);
+        unpack8t<T>(uint4{old[ct].x, old[ct].y, 0u, 0u}, o8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = Elem<T>::to_f32(Elem<T>::from_f32(m8[e] > 0.f ? acc[e] : 0.f)) + o8[e];
+#ifndef HB_EXP_NO_DX
+        if (pa.ok && c < a.C) store4<T>(dxp + c, v);
+#else
+        if (v[0] == 123.456f) store4<T>(dxp + c, v);
+#endif
+      }
+      // park this pixel's operands of the weight gradients (zero rows for pixels past the end)
+      const int row = s * 16 + li;
+      const uint4 z4 = {0u, 0u, 0u, 0u};
+      uint4 hs = pa.ok ? hid : z4;
+      if (pa.ok && q == (ONES >> 3)) {                 // the all-ones channel: slot ONES & 7 of k-group ONES >> 3
+        constexpr int OW = (ONES & 7) >> 1, OSH = ((ONES & 7) & 1) * 16;
+        const uint32_t one = (pack2<T>(1.f, 1.f) & 0xffffu) << OSH, keep = ~(0xffffu << OSH);
+        if (OW == 0) hs.x = (hs.x & keep) | one;
+        else if (OW == 1) hs.y = (hs.y & keep) | one;
+        else if (OW == 2) hs.z = (hs.z & keep) | one;
+        else hs.w = (hs.w & keep) | one;
+      }
+      *reinterpret_cast<uint4*>(s_hid + row * 64 + q * 16) = hs;
+      *reinterpret_cast<uint4*>(s_dl + row * 64 + q * 16) = pa.ok ? dl : z4;
+      *reinterpret_cast<uint4*>(s_dh + row * 64 + q * 16) = pa.ok ? dh : z4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(s_x + row * XROW + c * 64 + q * 16) = pa.ok ? xf[c] : z4;
+    }
+#ifndef HB_EXP_NO_WGRAD
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // weight gradients over these 32 pixels
+    uint4 fdl[NPT], fdh[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) { fdl[j] = strip_frag_tr(s_dl, 64, j, lane); fdh[j] = strip_frag_tr(s_dh, 64, j, lane); }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const uint4 fh = strip_frag_tr(s_hid, 64, i, lane);
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) g_wb[i][j] = mma16<T>(fh, fdl[j], g_wb[i][j]);         // dWb[pos m][pos n] (row ONES: d bb)
+      if (i == (ONES >> 4)) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) g_ba[j] = mma16<T>(fh, fdh[j], g_ba[j]);             // row ONES: d ba
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const uint4 fx = strip_frag_tr(s_x, XROW, ct, lane);
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) g_wa[ct][j] = mma16<T>(fx, fdh[j], g_wa[ct][j]);       // dWa[c][pos m]
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+  }
+
+  // flush.  Thousands of waves adding into the same few thousand addresses serialise in the L2 atomic units (measured: ~300 us per launch
+  // with one flush per wave), so the four waves of a workgroup first sum their tiles in LDS and wave 0 issues the global atomics.
+  // D tile (i, j): a lane holds rows i*16 + q*4 + e, column j*16 + li.
+  __syncthreads();                                     // every wave is done with its strip: the LDS is reused as [tile][256] fp32
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int NTILES = NPT * NPT + NPT + CT * NPT;
+  for (int i = threadIdx.x; i < NTILES * 256; i += BWD_WAVES * 64) red[i] = 0.f;
+  __syncthreads();
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+#pragma unroll
+      for (int j = 0; j < NPT; ++j, ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(red + t * 256 + e * 64 + lane, g_wb[i][j][e]);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j, ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(red + t * 256 + e * 64 + lane, g_ba[j][e]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int j = 0; j < NPT; ++j, ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(red + t * 256 + e * 64 + lane, g_wa[ct][j][e]);
+  }
+  __syncthreads();
+  // 256 threads walk the summed tiles: thread -> (element e, lane) of a tile, exactly the layout above
+  const int fl = threadIdx.x & 63, fe = threadIdx.x >> 6, fli = fl & 15, fq = fl >> 4;
+#ifndef HB_EXP_NO_FLUSH
+  if (threadIdx.x < 256) {
+    int t = 0;
+    for (int i = 0; i < NPT; ++i)
+      for (int j = 0; j < NPT; ++j, ++t) {
+        const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = i * 16 + fq * 4 + fe, m = pos_ch(pos);
+        const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
+        const float v = red[t * 256 + fe * 64 + fl];
+        if (!n_ok) continue;
+        if (pos == ONES) atomicAdd(a.dbb + n, v);
+        else if (((pos & 7) >> 2) < NT && m < K) atomicAdd(a.dwb + m * K + n, v);
+      }
+    for (int j = 0; j < NPT; ++j, ++t) {
+      const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = (ONES >> 4) * 16 + fq * 4 + fe;
+      const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
+      if (n_ok && pos == ONES) atomicAdd(a.dba + n, red[t * 256 + fe * 64 + fl]);
+    }
+    for (int ct = 0; ct < CT; ++ct)
+      for (int j = 0; j < NPT; ++j, ++t) {
+        const int cpos = j * 16 + fli, n = pos_ch(cpos), c = ct * 16 + fq * 4 + fe;
+        const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
+        if (n_ok && c < a.C) atomicAdd(a.dwa + (long)c * K + n, red[t * 256 + fe * 64 + fl]);
+      }
+  }
+#endif
+}
+
+int g_head_cus = 0;
+static int head_cus() {
+  if (g_head_cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&g_head_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_head_cus <= 0) g_head_cus = 256;
+  }
+  return g_head_cus;
+}
+
+template <typename T, int KS, int NCH>
+int launch_head(const HeadP& p, bool backward, hipStream_t s) {
+  const long groups = (p.npix + 15) / 16;
+  if (!backward) {
+    long wgs = (groups + 4 * 4 - 1) / (4 * 4);         // >= 4 groups of 16 pixels per wave: the weight gather is paid once per wave
+    const long cap = (long)head_cus() * 8;
+    if (wgs > cap) wgs = cap;
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL((head_fwd_kernel<T, KS, NCH>), dim3((unsigned)wgs), dim3(256), 0, s, p);
+  } else {
+    constexpr int STRIP = 32 * (3 * 64 + NCH * 64);
+    const size_t lds = BWD_WAVES * (size_t)STRIP + (size_t)(HeadDim<KS>::NT * NCH + NCH * 2) * 1024;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    long wgs = (long)head_cus();                       // persistent: one flush of the gradient tiles per workgroup
+    const long steps = (p.npix + 31) / 32;
+    if (wgs * BWD_WAVES > steps) wgs = (steps + BWD_WAVES - 1) / BWD_WAVES;
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL((head_bwd_kernel<T, KS, NCH>), dim3((unsigned)wgs), dim3(BWD_WAVES * 64), lds, s, p);
+  }
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+template <typename T, int KS>
+int dispatch_nch(const HeadP& p, bool backward, hipStream_t s) {
+  switch ((p.C + 31) / 32) {
+    case 1: return launch_head<T, KS, 1>(p, backward, s);
+    case 2: return launch_head<T, KS, 2>(p, backward, s);
+    case 3: return launch_head<T, KS, 3>(p, backward, s);
+    case 4: return launch_head<T, KS, 4>(p, backward, s);
+    default: dd_set_error("dd_kpcn_head: more than 128 input channels (%d) are not supported by the fused head", p.C); return DD_ERR_INVALID;
+  }
+}
+
+template <typename T>
+int dispatch_ks(const HeadP& p, int ks, bool backward, hipStream_t s) {
+  switch (ks) {
+    case 3: return dispatch_nch<T, 3>(p, backward, s);
+    case 5: return dispatch_nch<T, 5>(p, backward, s);
+    default: dd_set_error("dd_kpcn_head: kernel_size %d unsupported by the fused head (3, 5)", ks); return DD_ERR_INVALID;
+  }
+}
+
+int head_common(const dd_head_args* a, bool backward, dd_stream stream) {
+  DD_REQUIRE(a && a->x && a->src && a->wa && a->ba && a->wb && a->bb, "dd_kpcn_head: null pointer");
+  DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_kpcn_head: storage dtype must be DD_BF16 or DD_F16 (f32 runs layer by layer)");
+  DD_REQUIRE(a->C > 0 && a->C % 8 == 0 && a->ldx >= a->C && a->ldx % 8 == 0 && ((uintptr_t)a->x % 16) == 0, "dd_kpcn_head: C=%d ldx=%d must be multiples of 8, x 16-byte aligned", a->C, a->ldx);
+  DD_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->ldsrc >= 3, "dd_kpcn_head: bad shape");
+  DD_REQUIRE(a->H >= (a->ksize - 1) / 2 && a->W >= (a->ksize - 1) / 2, "dd_kpcn_head: image smaller than the symmetric pad");
+  HeadP p;
+  p.x = a->x; p.src = a->src; p.wa = a->wa; p.ba = a->ba; p.wb = a->wb; p.bb = a->bb; p.out = a->out;
+  p.dout = a->dout; p.dx = a->dx; p.dwa = a->dwa; p.dba = a->dba; p.dwb = a->dwb; p.dbb = a->dbb;
+  p.ldx = a->ldx; p.C = a->C; p.ldsrc = a->ldsrc; p.ldo = a->ld_out; p.lddo = a->ld_dout; p.lddx = a->ld_dx; p.accumulate = a->accumulate_dx;
+  p.N = a->N; p.H = a->H; p.W = a->W; p.npix = (long)a->N * a->H * a->W;
+  if (!backward) DD_REQUIRE(a->out && a->ld_out >= 3, "dd_kpcn_head_fwd: null output");
+  else DD_REQUIRE(a->dout && a->ld_dout >= 3 && a->dx && a->ld_dx >= a->C && a->ld_dx % 4 == 0 && a->dwa && a->dba && a->dwb && a->dbb, "dd_kpcn_head_bwd: null gradient pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return a->dtype == DD_BF16 ? dispatch_ks<bf16_t>(p, a->ksize, backward, s) : dispatch_ks<f16_t>(p, a->ksize, backward, s);
+}
+
+}  // namespace
+
+extern "C" int dd_kpcn_head_fwd(const dd_head_args* a, dd_stream stream) { return head_common(a, false, stream); }
+extern "C" int dd_kpcn_head_bwd(const dd_head_args* a, dd_stream stream) { return head_common(a, true, stream); }

@@ -131,6 +131,25 @@ int dd_kpcn_fwd(const float* src, int ldsrc, const void* logits, int ldl, float*
 int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
                 void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream);
 
+/* ---- the whole kernel-prediction head of one scale as ONE launch each way: AdjustNumberOfChannels.predict (Architecture.py:237-244:
+ * 1x1 conv C -> K + ReLU, 1x1 conv K -> K) + KernelPredictor.predict / KernelPrediction.kernel_prediction (Architecture.py:260-289,
+ * KernelPrediction.py:11-63) with K = ksize * ksize (one tuple member), and their TF-autodiff gradients.  bf16 / fp16 storage only.
+ * Weights are the fp32 master variables in TensorFlow layout (wa [C][K], wb [K][K]).  The backward recomputes hid / logits from x, so
+ * the forward stores nothing; dx (storage type) is masked by x > 0 (x is a ReLU output) and optionally accumulated into; the weight /
+ * bias gradients are ADDED to their fp32 arena slots. */
+typedef struct {
+  const void* x; int ldx; int C;           /* backbone output of this scale [N,H,W,ldx], C valid channels (C % 8 == 0, C <= 128) */
+  const float* src; int ldsrc;             /* 3-channel source at this scale [N,H,W,ldsrc] fp32 */
+  const float* wa; const float* ba; const float* wb; const float* bb;
+  float* out; int ld_out;                  /* forward: prediction [N,H,W,ld_out] fp32 (3 channels) */
+  const float* dout; int ld_dout;          /* backward: dL/d(out) fp32 */
+  void* dx; int ld_dx; int accumulate_dx;  /* backward: dL/dx (storage type) */
+  float* dwa; float* dba; float* dwb; float* dbb;
+  int N, H, W, ksize, dtype;
+} dd_head_args;
+int dd_kpcn_head_fwd(const dd_head_args* a, dd_stream stream);
+int dd_kpcn_head_bwd(const dd_head_args* a, dd_stream stream);
+
 /* ---- multiscale compose (MultiScalePrediction.compose_scales, MultiScalePrediction.py:36-54) */
 /* net input = concat(nearest_x2(small), fine), zero padded to c_pad channels */
 int dd_compose_pack(const float* small, int lds, const float* fine, int ldf, void* dst, int ld, int c_pad,

@@ -308,3 +308,57 @@ def test_fused_compose_net_matches_the_layerwise_path(dtype, shape, monkeypatch)
     print("compose backward vs layer-wise, %s %s: worst per-parameter gradient rel-L2 %.2e; whole gradient vs the f64 oracle: fused %.3e, layer-wise %.3e"
           % (dtype, shape, worst, e_fused, e_layer))
     assert e_fused <= 1.3 * e_layer + 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("ks,filters,shape", [(5, (16, 24, 32), (3, 24, 40)), (3, (16, 16), (2, 32, 16)), (5, (64, 96, 128), (1, 32, 32)), (5, (24, 40), (1, 20, 12))])
+def test_fused_kernel_prediction_head_matches_the_layerwise_path(dtype, ks, filters, shape, monkeypatch):
+    """csrc/dd_head.hip (1x1 -> ReLU -> 1x1 -> softmax -> k x k filter apply of a scale in one launch, backward with recompute in one more)
+    against the layer-by-layer lowering of the same storage type: predictions, loss, every gradient; and against the f64 oracle.
+    Channel counts 16 ... 128 (1 to 4 K-chunks, partial chunks), 3x3 and 5x5 kernels, pixel counts that are not multiples of 16 / 32."""
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    B, H, W = shape
+    aj = configs.architecture(filters=filters, convs=1, flag_mode="NONE", kernel_size=ks,
+                              combined={"Diffuse": {"Color": "Diffuse Color", "Direct": "Diffuse Direct", "Indirect": "Diffuse Indirect"}})
+    tj = configs.training(image_mean=0.0)
+    tj["combined_image_training_settings"]["statistics"]["track_mean"] = False
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(oracle, B, H, W)
+    preds_o = oracle.predict(feats)
+    _, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    dev, devl = {k: v.cuda() for k, v in feats.items()}, {k: v.cuda() for k, v in labels.items()}
+    runs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DD_FUSE_HEAD", fuse)
+        arch = Architecture(aj, device="cuda", dtype=dtype)
+        prog = arch.program(B, H, W, training_json=tj)
+        arch.params.load_list(list(oracle.vs.vars.values()))
+        assert prog.fused_head == (fuse == "1")
+        assert ("kpcn_head" in [getattr(op, "tag", "") for op in prog.g.fwd_ops]) == (fuse == "1")
+        assert ("kpcn_head" in [getattr(op, "tag", "") for op in prog.g.bwd_ops]) == (fuse == "1")
+        loss = float(prog.train_step(dev, devl))
+        torch.cuda.synchronize()
+        preds = [{k: v.clone() for k, v in d.items()} for d in prog.prediction_dictionaries()]
+        runs[fuse] = (preds, loss, arch.params.grads.clone() / prog.loss_scale)
+    tol = {"bf16": 4e-3, "f16": 5e-4}[dtype]
+    (p0, l0, g0), (p1, l1, g1) = runs["0"], runs["1"]
+    for s in range(len(p0)):
+        for k in p0[s]:
+            assert rel_l2(p1[s][k], p0[s][k]) < tol, (s, k, rel_l2(p1[s][k], p0[s][k]))
+            # the storage type's own distance from the f64 oracle (large for these tiny random nets: the softmax amplifies logit rounding):
+            # the fused path must not be further away than the layer-wise one
+            assert rel_l2(p1[s][k].cpu(), preds_o[s][k]) <= 1.2 * rel_l2(p0[s][k].cpu(), preds_o[s][k]) + tol
+    assert abs(l1 - l0) <= tol * abs(l0)
+    go = torch.zeros_like(g0.cpu(), dtype=torch.float64)
+    worst = 0.0
+    for q, t in zip(arch.params.params, grads_o):
+        go[q.offset:q.offset + q.size] = t.reshape(-1)
+        a, b_ = g1[q.offset:q.offset + q.size], g0[q.offset:q.offset + q.size]
+        if float(b_.norm()) > 0:
+            worst = max(worst, rel_l2(a, b_))
+            assert rel_l2(a, b_) < 25 * tol, (q.name, rel_l2(a, b_))
+    e_fused, e_layer = rel_l2(g1.cpu(), go), rel_l2(g0.cpu(), go)
+    print("fused head vs layer-wise, %s k=%d %s: worst per-parameter gradient rel-L2 %.2e; whole gradient vs the f64 oracle: fused %.3e, layer-wise %.3e"
+          % (dtype, ks, shape, worst, e_fused, e_layer))
+    assert e_fused <= 1.3 * e_layer + 1e-4
