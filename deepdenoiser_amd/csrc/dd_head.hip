@@ -41,25 +41,74 @@ __device__ __forceinline__ int pos_ch(int pos) { return slot_ch(pos >> 3, pos & 
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_tr16_ptr;
 
+// Work unit: a SEGMENT = 16 consecutive pixels of one image row (lane li <-> x = 16 * sx + li).  A wave walks a contiguous range of segments in
+// (image, row, x-segment) order, so the position advances with compares and adds on wave-uniform values -- no per-lane division of a linear
+// pixel index (the first version spent most of its ~1 700 VALU instructions per 32 pixels on exactly that and on 64-bit address arithmetic).
+struct SegWalk {
+  int b, y, sx;          // wave-uniform
+  long left;             // segments left in this wave's range
+};
+__device__ __forceinline__ SegWalk seg_start(long first, long count, long nsegs, int nseg_x, int H) {
+  SegWalk w;
+  if (first > nsegs) first = nsegs;
+  w.left = first + count <= nsegs ? count : nsegs - first;
+  const long row = first / nseg_x;
+  w.sx = (int)(first - row * nseg_x);
+  w.b = (int)(row / H);
+  w.y = (int)(row - (long)w.b * H);
+  return w;
+}
+__device__ __forceinline__ void seg_next(SegWalk& w, int nseg_x, int H) {
+  --w.left;
+  if (++w.sx == nseg_x) { w.sx = 0; if (++w.y == H) { w.y = 0; ++w.b; } }
+}
 struct PixelAddr { int b, y, x; bool ok; };
-__device__ __forceinline__ PixelAddr pixel_of(long p, const HeadP& a) {
+// this lane's pixel of the walker's current segment (clamped into the image when the segment is ragged or the range is exhausted)
+__device__ __forceinline__ PixelAddr seg_pixel(const SegWalk& w, int li, const HeadP& a) {
   PixelAddr r;
-  r.ok = p < a.npix;
-  const long pc = r.ok ? p : a.npix - 1;
-  r.x = (int)(pc % a.W);
-  const long t = pc / a.W;
-  r.y = (int)(t % a.H);
-  r.b = (int)(t / a.H);
+  const bool live = w.left > 0;
+  r.b = live ? w.b : 0;
+  r.y = live ? w.y : 0;
+  const int x = w.sx * 16 + li;
+  r.ok = live && x < a.W;
+  r.x = r.ok ? x : 0;
   return r;
 }
 __device__ __forceinline__ int sym(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
+// element offsets of the taps this lane's channels stand for (channel t <-> tap (t / KS, t % KS); channels >= K re-read tap 0, their weight is 0):
+// (ty << 8) | tx per (tile j, element e), fixed for the lane
+template <int KS>
+__device__ __forceinline__ void lane_taps(int (&tyx)[HeadDim<KS>::NT][4], int q) {
+#pragma unroll
+  for (int j = 0; j < HeadDim<KS>::NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t0 = j * 16 + q * 4 + e, t = t0 < HeadDim<KS>::K ? t0 : 0;
+      tyx[j][e] = ((t / KS) << 8) | (t % KS);
+    }
+}
+// the three source channels of every tap of this lane, all requested back to back (32-bit offsets from the image's base)
+template <int KS>
+__device__ __forceinline__ void load_taps(float (&sv)[HeadDim<KS>::NT][4][3], const int (&tyx)[HeadDim<KS>::NT][4], const float* img, const PixelAddr& pa,
+                                          const HeadP& a) {
+  constexpr int P = HeadDim<KS>::P;
+#pragma unroll
+  for (int j = 0; j < HeadDim<KS>::NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int sy = sym(pa.y + (tyx[j][e] >> 8) - P, a.H), sx = sym(pa.x + (tyx[j][e] & 255) - P, a.W);
+      const float* sp = img + (unsigned)((sy * a.W + sx) * a.ldsrc);
+      sv[j][e][0] = sp[0]; sv[j][e][1] = sp[1]; sv[j][e][2] = sp[2];
+    }
+}
 
-// The weight fragments of the two forward GEMMs, gathered once per wave from the fp32 master variables (TensorFlow layout [C][K], [K][K]).
+// The weight fragments of the two forward GEMMs, built once per wave from the fp32 master variables (TensorFlow layout [C][K], [K][K]).
 template <typename T, int KS, int NCH> struct FwdWeights {
   uint4 a1[HeadDim<KS>::NT][NCH];   // GEMM 1: row n = j*16 + li, k = c*32 + q*8 + e          -> Wa[k][n]
   uint4 a2[HeadDim<KS>::NT];        // GEMM 2: row n = j*16 + li, k-slot (q, e) = channel slot_ch -> Wb[slot_ch][n]
   float b1[HeadDim<KS>::NT][4], b2[HeadDim<KS>::NT][4];      // biases of this lane's result channels j*16 + q*4 + e
 };
+
 // The fp32 master weights, staged ONCE per workgroup into LDS with coalesced loads: [Wa (C x K) | Wb (K x K) | ba | bb].  A lane's fragment
 // elements are K floats apart (100 bytes for K = 25): gathered straight from global memory every wave-instruction touches ~50 cache lines,
 // and with every wave of the launch doing it at once that alone was ~70 us per launch; from LDS the odd stride is conflict-free.
@@ -183,36 +232,32 @@ __device__ __forceinline__ void softmax4(float (&lg)[HeadDim<KS>::NT][4], int q)
 // ------------------------------------------------------------------------------------------------------------------------ forward
 template <typename T, int KS, int NCH>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadP a) {
-  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, P = HeadDim<KS>::P;
+  constexpr int NT = HeadDim<KS>::NT;
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   __shared__ float s_w[128 * HeadDim<KS>::K + HeadDim<KS>::K * HeadDim<KS>::K + 2 * HeadDim<KS>::K];
   const HeadW hw = stage_head_weights<KS>(s_w, a, 256);
   FwdWeights<T, KS, NCH> w;
   load_fwd_weights<T, KS, NCH>(w, hw, li, q);
-  const long ngroups = (a.npix + 15) >> 4;
-  for (long grp = wave; grp < ngroups; grp += nwaves) {
-    const PixelAddr pa = pixel_of(grp * 16 + li, a);
-    const long pix = ((long)pa.b * a.H + pa.y) * a.W + pa.x;
+  int tyx[NT][4];
+  lane_taps<KS>(tyx, q);
+  const int nseg_x = (a.W + 15) >> 4;
+  const long nsegs = (long)a.N * a.H * nseg_x, per_wave = (nsegs + nwaves - 1) / nwaves;
+  SegWalk sw = seg_start(wave * per_wave, per_wave, nsegs, nseg_x, a.H);
+  for (; sw.left > 0; seg_next(sw, nseg_x, a.H)) {
+    const PixelAddr pa = seg_pixel(sw, li, a);
+    const int pix = (pa.b * a.H + pa.y) * a.W + pa.x;                    // (npix < 2^31: checked by the host)
     uint4 xf[NCH];
     load_x<T, NCH>(xf, a, pix, q);
-    uint4 hid;
-    float p[NT][4];
-    forward_gemms<T, KS, NCH>(w, xf, hid, p);
-    softmax4<KS>(p, q);
     const float* img = a.src + (long)pa.b * a.H * a.W * a.ldsrc;
     // the taps this lane's channels stand for.  Every load is unconditional (channels >= K re-read tap 0 with weight 0): a branch per tap
     // would put a full memory round trip behind each of them instead of one behind all
     float sv[NT][4][3];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int t0 = j * 16 + q * 4 + e, t = t0 < K ? t0 : 0;
-        const int ty = t / KS, tx = t - ty * KS;
-        const float* s = img + ((long)sym(pa.y + ty - P, a.H) * a.W + sym(pa.x + tx - P, a.W)) * a.ldsrc;
-        sv[j][e][0] = s[0]; sv[j][e][1] = s[1]; sv[j][e][2] = s[2];
-      }
+    load_taps<KS>(sv, tyx, img, pa, a);
+    uint4 hid;
+    float p[NT][4];
+    forward_gemms<T, KS, NCH>(w, xf, hid, p);
+    softmax4<KS>(p, q);
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -221,7 +266,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadP a) {
     o0 += __shfl_xor(o0, 16); o0 += __shfl_xor(o0, 32);
     o1 += __shfl_xor(o1, 16); o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 16); o2 += __shfl_xor(o2, 32);
-    if (pa.ok && q < 3) a.out[pix * a.ldo + q] = q == 0 ? o0 : (q == 1 ? o1 : o2);
+    if (pa.ok && q < 3) a.out[(long)pix * a.ldo + q] = q == 0 ? o0 : (q == 1 ? o1 : o2);
   }
 }
 
@@ -314,52 +359,54 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
 #pragma unroll
     for (int j = 0; j < NPT; ++j) g_wa[ct][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // A step = two consecutive segments (32 pixels: one K-step of the weight-gradient MFMAs); each wave walks a contiguous range of them.
+  int tyx[NT][4];
+  lane_taps<KS>(tyx, q);
+  const int nseg_x = (a.W + 15) >> 4;
+  const long nsegs = (long)a.N * a.H * nseg_x;
 #ifdef HB_EXP_NO_LOOP
-  const long nsteps = 0;
+  const long per_wave = 0;
 #else
-  const long nsteps = (a.npix + 31) >> 5;
+  const long per_wave = ((nsegs + nwaves - 1) / nwaves + 1) & ~1L;      // even: a wave's range is whole steps
 #endif
-  // x of the NEXT 16-pixel subgroup is requested one subgroup ahead (the HBM round trip); everything else a subgroup reads (d out, source
-  // taps, ReLU masks, the gradient it accumulates into) is requested together at its top: one exposed round trip per subgroup, not five.
+  SegWalk sw = seg_start(wave * per_wave, per_wave, nsegs, nseg_x, a.H);
+  // x of the NEXT segment is requested one segment ahead (the HBM round trip); everything else a segment reads (d out, source taps, ReLU
+  // masks, the gradient it accumulates into) is requested together at its top: one exposed round trip per segment, not five.
   uint4 xnext[NCH];
   {
-    const PixelAddr p0 = pixel_of(wave * 32 + li, a);
-    load_x<T, NCH>(xnext, a, ((long)p0.b * a.H + p0.y) * a.W + p0.x, q);
+    const PixelAddr p0 = seg_pixel(sw, li, a);
+    load_x<T, NCH>(xnext, a, (p0.b * a.H + p0.y) * a.W + p0.x, q);
   }
-  for (long step = wave; step < nsteps; step += nwaves) {
+  while (sw.left > 0) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const PixelAddr pa = pixel_of(step * 32 + s * 16 + li, a);
-      const long pix = ((long)pa.b * a.H + pa.y) * a.W + pa.x;
+      const PixelAddr pa = seg_pixel(sw, li, a);
+      const int pix = (pa.b * a.H + pa.y) * a.W + pa.x;
+      seg_next(sw, nseg_x, a.H);                       // (past the end of the range seg_pixel clamps to pixel 0 and clears `ok`)
       uint4 xf[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) xf[c] = xnext[c];
       {
-        const long nstep = s == 0 ? step : step + nwaves;
-        const PixelAddr pn = pixel_of(nstep * 32 + (1 - s) * 16 + li, a);          // (clamped to the last pixel past the end)
-        load_x<T, NCH>(xnext, a, ((long)pn.b * a.H + pn.y) * a.W + pn.x, q);
+        const PixelAddr pn = seg_pixel(sw, li, a);
+        load_x<T, NCH>(xnext, a, (pn.b * a.H + pn.y) * a.W + pn.x, q);
       }
-      // (every load below is unconditional: pixels past the end were clamped by pixel_of and are masked by `okf`, channels >= K re-read
-      //  tap 0 and carry p = 0 -- see the forward kernel)
+      // (every load below is unconditional: ragged / exhausted segments were clamped by seg_pixel and are masked by `okf`, channels >= K
+      //  re-read tap 0 and carry p = 0 -- see the forward kernel)
       const float okf = pa.ok ? 1.f : 0.f;
-      const float g0 = okf * a.dout[pix * a.lddo], g1 = okf * a.dout[pix * a.lddo + 1], g2 = okf * a.dout[pix * a.lddo + 2];
+      const float* dop = a.dout + (long)pix * a.lddo;
+      const float g0 = okf * dop[0], g1 = okf * dop[1], g2 = okf * dop[2];
       const float* img = a.src + (long)pa.b * a.H * a.W * a.ldsrc;
       float sv[NT][4][3];
+#ifdef HB_EXP_NO_TAPS
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int t0 = j * 16 + q * 4 + e, t = t0 < K ? t0 : 0;
-          const int ty = t / KS, tx = t - ty * KS;
-          const float* sp = img + ((long)sym(pa.y + ty - P, a.H) * a.W + sym(pa.x + tx - P, a.W)) * a.ldsrc;
-#ifdef HB_EXP_NO_TAPS
-          sv[j][e][0] = (float)t; sv[j][e][1] = 1.f; sv[j][e][2] = (float)(size_t)sp * 0.f;
+        for (int e = 0; e < 4; ++e) { sv[j][e][0] = (float)tyx[j][e]; sv[j][e][1] = 1.f; sv[j][e][2] = (float)(size_t)img * 0.f; }
 #else
-          sv[j][e][0] = sp[0]; sv[j][e][1] = sp[1]; sv[j][e][2] = sp[2];
+      load_taps<KS>(sv, tyx, img, pa, a);
 #endif
-        }
-      T* dxp = reinterpret_cast<T*>(a.dx) + pix * a.lddx;
-      const T* xp = reinterpret_cast<const T*>(a.x) + pix * a.ldx;
+      T* dxp = reinterpret_cast<T*>(a.dx) + (long)pix * a.lddx;
+      const T* xp = reinterpret_cast<const T*>(a.x) + (long)pix * a.ldx;
       uint2 xm[CT], old[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -371,7 +418,6 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
         old[ct] = a.accumulate ? *reinterpret_cast<const uint2*>(dxp + cc) : uint2{0u, 0u};
 #endif
       }
-      __builtin_amdgcn_sched_barrier(0);               // all of the above is in flight before the first MFMA waits for x
 
       uint4 hid;
       float p[NT][4];
