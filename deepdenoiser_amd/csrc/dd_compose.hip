@@ -20,6 +20,21 @@
 // Zero padding is TensorFlow's: every conv pads ITS input, so each layer's frame is forced to zero outside the image.
 #include "dd_common.h"
 
+#ifdef DD_PROFILE_PHASES
+// cycle stamps of workgroup 0 (tools/compose_phases.py): slot i accumulates the cycles between stamp i-1 and stamp i of the chosen thread
+__device__ unsigned long long dd_cphase[64];
+#define CPH_DECL(t) unsigned long long cph_last = __builtin_readcyclecounter(); const bool cph_on = blockIdx.x == 0 && threadIdx.x == (t)
+#define CPH(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (cph_on) dd_cphase[i] += now_ - cph_last; cph_last = now_; } while (0)
+extern "C" int dd_debug_cphases(unsigned long long* out64, int reset) {
+  if (out64) (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(dd_cphase), sizeof(unsigned long long) * 64);
+  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_cphase), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define CPH_DECL(t)
+#define CPH(i)
+#endif
+
 namespace {
 
 constexpr int FR = 24;                      // frame side: 16 + 2 * 4
@@ -155,23 +170,47 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
   __syncthreads();
 
   const int per_img = p.tiles_y * p.tiles_x;
+  const int H = p.H, W = p.W, h2 = H >> 1, w2 = W >> 1;
+  // The net input of the NEXT tile (6 fp32 values for each of this thread's 1-2 frame pixels) is requested while the current tile's four
+  // conv layers run: with the loads in front of layer 0 every tile started with an exposed memory round trip (~2 us of ~13).
+  constexpr int NPF = (FR * FR + 511) / 512;
+  float xin[NPF][6];
+  auto load_x0 = [&](int tile) {
+    const int tt = tile < p.total_tiles ? tile : p.total_tiles - 1;
+    const int b = tt / per_img, rem = tt - b * per_img, ty = rem / p.tiles_x;
+    const int y0 = ty * 16, x0 = (rem - ty * p.tiles_x) * 16;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = tid + i * 512;
+      const int fy = idx / FR, fx = idx - fy * FR;
+      const int gy = y0 - 4 + fy, gx = x0 - 4 + fx;
+      const bool inside = idx < FR * FR && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const int cy = inside ? gy : 0, cx = inside ? gx : 0;              // unconditional loads from a clamped pixel, zeroed below
+      const float* s = p.small + (((long)b * h2 + (cy >> 1)) * w2 + (cx >> 1)) * p.ld_small;
+      const float* f = p.fine + (((long)b * H + cy) * W + cx) * p.ld_fine;
+      const float m = inside ? 1.f : 0.f;
+      xin[i][0] = m * s[0]; xin[i][1] = m * s[1]; xin[i][2] = m * s[2]; xin[i][3] = m * f[0]; xin[i][4] = m * f[1]; xin[i][5] = m * f[2];
+    }
+  };
+  load_x0(blockIdx.x);
+  CPH_DECL(0);
   for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    CPH(0);
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / p.tiles_x;
     const int y0 = ty * 16, x0 = (rem - ty * p.tiles_x) * 16;
-    const int H = p.H, W = p.W, h2 = H >> 1, w2 = W >> 1;
 
     // ---------------------------------------------------------------- layer 0: x0 -> a1 = relu(1x1) on the whole 24x24 frame
-    for (int idx = tid; idx < FR * FR; idx += 512) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = tid + i * 512;
+      if (idx >= FR * FR) continue;
       const int fy = idx / FR, fx = idx - fy * FR;
       const int gy = y0 - 4 + fy, gx = x0 - 4 + fx;
       const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (inside) {
-        const float* s = p.small + (((long)b * h2 + (gy >> 1)) * w2 + (gx >> 1)) * p.ld_small;
-        const float* f = p.fine + (((long)b * H + gy) * W + gx) * p.ld_fine;
-        x[0] = s[0]; x[1] = s[1]; x[2] = s[2]; x[3] = f[0]; x[4] = f[1]; x[5] = f[2];
-      }
+      float x[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = xin[i][k];
       const bool interior = fy >= 4 && fy < 20 && fx >= 4 && fx < 20;
       if (interior) {
         float* st = stash + ((fy - 4) * 16 + (fx - 4)) * 6;
@@ -204,18 +243,30 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
       uint4* dst = reinterpret_cast<uint4*>(bufA + idx * PIXB);
       dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
+    CPH(1);
     __syncthreads();
+    CPH(2);
+    load_x0(tile + gridDim.x);                             // in flight during the conv layers of this tile
     save_interior(bufA, p.save_act[0], p.ld_act[0], b, y0, x0, H, W, tid);
-
+    CPH(3);
     conv_layer<T, 1, false, false>(bufA, bufB, nullptr, wts, b_res, koff, y0, x0, H, W, wave, li, q);                 // relu(r1)
+    CPH(4);
     __syncthreads();
+    CPH(5);
     save_interior(bufB, p.save_act[1], p.ld_act[1], b, y0, x0, H, W, tid);
+    CPH(6);
     conv_layer<T, 2, false, true>(bufB, bufC, bufA, wts + WL_BYTES, b_res + 24, koff, y0, x0, H, W, wave, li, q);     // a2 = a1 + conv
+    CPH(7);
     __syncthreads();
+    CPH(8);
     save_interior(bufC, p.save_act[2], p.ld_act[2], b, y0, x0, H, W, tid);
+    CPH(9);
     conv_layer<T, 3, true, false>(bufC, bufB, nullptr, wts + 2 * WL_BYTES, b_res + 48, koff, y0, x0, H, W, wave, li, q);   // relu(r3)
+    CPH(10);
     __syncthreads();
+    CPH(11);
     save_interior(bufB, p.save_act[3], p.ld_act[3], b, y0, x0, H, W, tid);
+    CPH(12);
 
     // ---------------------------------------------------------------- layer 4 on the 16x16 interior + 1x1 -> sigmoid -> blend
     {
@@ -277,7 +328,12 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
         }
       }
     }
+    CPH(13);
     __syncthreads();      // bufB / bufC / stash are rewritten by the next tile
+    CPH(14);
+#ifdef DD_PROFILE_PHASES
+    if (cph_on) dd_cphase[15] += 1;
+#endif
   }
 }
 
@@ -342,18 +398,23 @@ __device__ __forceinline__ uint4 frame_frag_tr(const char* frame, int kst, int s
   return r;
 }
 
-// Weight gradient of one 3x3 layer for this tile's 256 interior pixels: acc[tap] += act[p + tap] (x) dc[p].
-// A weight-gradient wave owns input-channel tile mi and output-channel tile nj of ALL nine taps.
+// Weight gradient of one 3x3 layer for this tile's 256 interior pixels: acc[i] += act[p + tap_i] (x) dc[p].
+// A weight-gradient wave owns input-channel tile mi, output-channel tile nj and tap group tg (0: taps 0..4, 1: taps 5..8).
 template <typename T, bool RELU_A>
-__device__ __forceinline__ void wgrad_stage(f32x4_t (&acc)[9], const char* act, const char* dc, int mi, int nj, int lane) {
+__device__ __forceinline__ void wgrad_stage(f32x4_t (&acc)[5], const char* act, const char* dc, int mi, int nj, int tg, int lane) {
   const uint32_t one2 = pack2<T>(1.f, 1.f);
-  const bool ones_lane = mi == 1 && (lane & 15) == 8;      // channel 24 := 1  =>  row 24 of the centre-tap tile = bias gradient
+  const bool ones_lane = mi == 1 && tg == 0 && (lane & 15) == 8;      // channel 24 := 1  =>  row 24 of the centre-tap tile = bias gradient
   // this lane's part of every transposed fragment read (frame_frag_tr): pixel (g >> 1, (g & 1) * 8 + (t16 >> 2)) of the k-step, channel quad
-  // t16 & 3; k-step, tap shift and the +4-pixel second half are immediates on top of TWO address registers
+  // t16 & 3; k-step and the +4-pixel second half are immediates on top of a few address registers
   const int t16 = lane & 15, g = lane >> 4;
   const int loff = ((4 + (g >> 1)) * FR + 4 + (g & 1) * 8 + (t16 >> 2)) * PIXB + (t16 & 3) * 8;
-  const char* pa = act + loff + mi * 32;
   const char* pq = dc + loff + nj * 32;
+  const char* pa[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int tap = min(tg * 5 + i, 8);
+    pa[i] = act + loff + mi * 32 + ((tap / 3 - 1) * FR + (tap % 3 - 1)) * PIXB;
+  }
   auto tr = [](const char* a) {
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a));
     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + 4 * PIXB));
@@ -366,49 +427,58 @@ __device__ __forceinline__ void wgrad_stage(f32x4_t (&acc)[9], const char* act, 
   };
 #pragma unroll 1
   for (int kst = 0; kst < 8; ++kst) {
-    const uint4 bq = tr(pq);
+    const int koffs = kst * 2 * FR * PIXB;
+    const uint4 bq = tr(pq + koffs);
 #pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3) {              // one tap row at a time: 3 fragments in flight next to the 144 accumulator registers
+    for (int i0 = 0; i0 < 5; i0 += 3) {             // 3 + 2 fragments at a time: 80 accumulator registers leave room for little else
       uint4 ap[3];
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        ap[dx] = tr(pa + ((t3 - 1) * FR + (dx - 1)) * PIXB);
-        if (RELU_A) ap[dx] = relu16<T>(ap[dx]);
+      for (int i = i0; i < i0 + 3 && i < 5; ++i) {
+        ap[i - i0] = tr(pa[i] + koffs);
+        if (RELU_A) ap[i - i0] = relu16<T>(ap[i - i0]);
+        if (i == 4 && ones_lane) ap[i - i0] = uint4{one2, one2, one2, one2};      // tap group 0, slot 4 = the centre tap
       }
-      if (t3 == 1 && ones_lane) ap[1] = uint4{one2, one2, one2, one2};
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) acc[t3 * 3 + dx] = mma16<T>(ap[dx], bq, acc[t3 * 3 + dx]);
+      for (int i = i0; i < i0 + 3 && i < 5; ++i)
+        if (i < 4 || tg == 0) acc[i] = mma16<T>(ap[i - i0], bq, acc[i]);
     }
-    pa += 2 * FR * PIXB;
-    pq += 2 * FR * PIXB;
   }
 }
 
 // Data gradient of one 3x3 layer on the frame (the forward's geometry: reads `in` on [L-1, 25-L)^2, writes `out` on [L, 24-L)^2),
-// run by the four data-gradient waves (w4 = 0..3).
+// run by the eight data-gradient waves (w8 = 0..7).
 //   MODE 0: out = conv . [mask > 0]       MODE 1: out = res + conv . [mask > 0]       MODE 2: out = (res + conv) . [mask > 0]
 template <typename T, int L, int MODE>
 __device__ __forceinline__ void dgrad_layer(const char* in, char* out, const char* res, const char* mask, const char* wl,
-                                            const int (&koff)[NCHUNK], int w4, int li, int q) {
+                                            const int (&koff)[NCHUNK], int w8, int li, int q) {
   constexpr int R = FR - 2 * L, NPIX = R * R, CHUNKS = (NPIX + 15) / 16;
-  uint4 wf[2][NCHUNK];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) wf[j][c] = *reinterpret_cast<const uint4*>(wl + c * 2048 + w_off(j * 16 + li, q));
-  for (int chunk = w4; chunk < CHUNKS; chunk += 4) {
+  // (4 waves per SIMD = 128 registers per wave: the weight fragments are re-read from LDS for every chunk, two K-chunks ahead of their MFMAs)
+  const char* w0 = wl + w_off(li, q);
+  const char* w1 = wl + w_off(16 + li, q);
+  for (int chunk = w8; chunk < CHUNKS; chunk += 8) {
     const int P = chunk * 16 + li;
     const int Pc = P < NPIX ? P : NPIX - 1;
     const int y = Pc / R, x = Pc - y * R;
     const char* base = in + ((L - 1 + y) * FR + (L - 1 + x)) * PIXB;
-    uint4 bf[NCHUNK];
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) bf[c] = *reinterpret_cast<const uint4*>(base + koff[c]);
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    uint4 bf[3], wa[3], wb[3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf[c] = *reinterpret_cast<const uint4*>(base + koff[c]);
+      wa[c] = *reinterpret_cast<const uint4*>(w0 + c * 2048);
+      wb[c] = *reinterpret_cast<const uint4*>(w1 + c * 2048);
+    }
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
-      a0 = mma16<T>(wf[0][c], bf[c], a0);
-      a1 = mma16<T>(wf[1][c], bf[c], a1);
+      if (c + 2 < NCHUNK) {
+        bf[(c + 2) % 3] = *reinterpret_cast<const uint4*>(base + koff[c + 2]);
+        wa[(c + 2) % 3] = *reinterpret_cast<const uint4*>(w0 + (c + 2) * 2048);
+        wb[(c + 2) % 3] = *reinterpret_cast<const uint4*>(w1 + (c + 2) * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = mma16<T>(wa[c % 3], bf[c % 3], a0);
+      a1 = mma16<T>(wb[c % 3], bf[c % 3], a1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const int po = ((L + y) * FR + (L + x)) * PIXB;
 #pragma unroll
@@ -430,15 +500,16 @@ __device__ __forceinline__ void dgrad_layer(const char* in, char* out, const cha
 }
 
 // Activation frame of one stage: region [LO, 24-LO)^2 of the 24x24 frame, 3 x 16 bytes per pixel, zeros outside the image.
-template <int LO> struct ActRegion { static constexpr int R = FR - 2 * LO, NV = R * R * 3, ITERS = (NV + 511) / 512; };
+constexpr int BWD_THREADS = 1024;      // 16 waves: 8 data-gradient + 8 weight-gradient (4 per SIMD; every phase of this kernel is latency-bound)
+template <int LO> struct ActRegion { static constexpr int R = FR - 2 * LO, NV = R * R * 3, ITERS = (NV + BWD_THREADS - 1) / BWD_THREADS; };
 template <int LO>
-__device__ __forceinline__ void act_load(uint4 (&pre)[3], const void* src, int ld, int b, int y0, int x0, int H, int W, int tid) {
+__device__ __forceinline__ void act_load(uint4 (&pre)[2], const void* src, int ld, int b, int y0, int x0, int H, int W, int tid) {
   constexpr int R = ActRegion<LO>::R, NV = ActRegion<LO>::NV;
   const char* base = reinterpret_cast<const char*>(src);
   const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
 #pragma unroll
   for (int it = 0; it < ActRegion<LO>::ITERS; ++it) {
-    const int v = tid + it * 512;
+    const int v = tid + it * BWD_THREADS;
     const int px = v / 3, slot = v - px * 3;
     const int fy = LO + px / R, fx = LO + px % R;
     const int gy = y0 - 4 + fy, gx = x0 - 4 + fx;
@@ -447,11 +518,11 @@ __device__ __forceinline__ void act_load(uint4 (&pre)[3], const void* src, int l
   }
 }
 template <int LO>
-__device__ __forceinline__ void act_store(char* buf, const uint4 (&pre)[3], int tid) {
+__device__ __forceinline__ void act_store(char* buf, const uint4 (&pre)[2], int tid) {
   constexpr int R = ActRegion<LO>::R, NV = ActRegion<LO>::NV;
 #pragma unroll
   for (int it = 0; it < ActRegion<LO>::ITERS; ++it) {
-    const int v = tid + it * 512;
+    const int v = tid + it * BWD_THREADS;
     const int px = v / 3, slot = v - px * 3;
     const int fy = LO + px / R, fx = LO + px % R;
     if (v < NV) *reinterpret_cast<uint4*>(buf + (fy * FR + fx) * PIXB + slot * 16) = pre[it];
@@ -515,86 +586,103 @@ __device__ __forceinline__ void s0_pixel(const ComposeBwdP& p, const BwdLds& m, 
 // acc1 / acc6: the two 1x1 layers' weight gradients of threads 0..191 (channel tid % 24, interior rows tid / 24 and + 8), reduced by the caller.
 template <typename T, bool WROLE>
 __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, const int (&koff)[NCHUNK], float (&acc1)[7], float& acc6, float& accb6) {
-  const int tid = threadIdx.x, lane = tid & 63, w4 = (tid >> 6) & 3, li = lane & 15, q = lane >> 4;
-  const int mi = w4 & 1, nj = w4 >> 1;
-  f32x4_t wacc[WROLE ? 4 : 1][9];
+  const int tid = threadIdx.x, lane = tid & 63, w8 = (tid >> 6) & 7, li = lane & 15, q = lane >> 4;
+  const int mi = w8 & 1, nj = (w8 >> 1) & 1, tg = w8 >> 2;
+  f32x4_t wacc[WROLE ? 4 : 1][5];
   if (WROLE) {
 #pragma unroll
     for (int l = 0; l < 4; ++l)
 #pragma unroll
-      for (int i = 0; i < 9; ++i) wacc[l][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 5; ++i) wacc[l][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
   const int per_img = p.tiles_y * p.tiles_x;
   const int H = p.H, W = p.W, h2 = H >> 1, w2 = W >> 1;
+  CPH_DECL(WROLE ? 512 : 0);
+  constexpr int PB = WROLE ? 40 : 16;      // slots of this role's stamps
   for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    CPH(PB + 0);
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / p.tiles_x;
     const int y0 = ty * 16, x0 = (rem - ty * p.tiles_x) * 16;
-    uint4 pre[3];
+    uint4 pre[2];
     act_load<1>(pre, p.act[3], p.ld_act[3], b, y0, x0, H, W, tid);          // relu(r3), needed from S1 on
     // ---------------------------------------------------------------- S0: blend + sigmoid + 1x1 backward on the whole frame
 #ifndef CB_EXP_NO_S0
-    s0_pixel<T>(p, m, tid, b, y0, x0);
-    if (tid < FR * FR - 512) s0_pixel<T>(p, m, tid + 512, b, y0, x0);
+    if (!WROLE) {                                           // (the weight-gradient role's registers are taken by its accumulators)
+      s0_pixel<T>(p, m, tid, b, y0, x0);
+      if (tid < FR * FR - 512) s0_pixel<T>(p, m, tid + 512, b, y0, x0);
+    }
+    CPH(PB + 1);
 #endif
     act_store<1>(m.bufAct, pre, tid);
+    CPH(PB + 2);
     __syncthreads();
+    CPH(PB + 3);
     // ---------------------------------------------------------------- S1: layer 4 (input relu(r3), output gradient dA)
     act_load<2>(pre, p.act[2], p.ld_act[2], b, y0, x0, H, W, tid);          // a2 for S2
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[WROLE ? 3 : 0], m.bufAct, m.bufG0, mi, nj, lane)); }
-    else { CB_DGRAD(dgrad_layer<T, 1, 0>(m.bufG0, m.bufG1, nullptr, m.bufAct, m.wts + 3 * WL_BYTES, koff, w4, li, q)); }
+    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[WROLE ? 3 : 0], m.bufAct, m.bufG0, mi, nj, tg, lane)); }
+    else { CB_DGRAD(dgrad_layer<T, 1, 0>(m.bufG0, m.bufG1, nullptr, m.bufAct, m.wts + 3 * WL_BYTES, koff, w8, li, q)); }
+    CPH(PB + 4);
     __syncthreads();
+    CPH(PB + 5);
     act_store<2>(m.bufAct, pre, tid);
+    CPH(PB + 6);
     __syncthreads();
+    CPH(PB + 7);
     // ---------------------------------------------------------------- S2: layer 3 (input relu(a2), output gradient dc3)
     act_load<3>(pre, p.act[1], p.ld_act[1], b, y0, x0, H, W, tid);          // relu(r1) for S3
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, true>(wacc[WROLE ? 2 : 0], m.bufAct, m.bufG1, mi, nj, lane)); }
-    else { CB_DGRAD(dgrad_layer<T, 2, 1>(m.bufG1, m.bufG0, m.bufG0, m.bufAct, m.wts + 2 * WL_BYTES, koff, w4, li, q)); }
+    if (WROLE) { CB_WGRAD(wgrad_stage<T, true>(wacc[WROLE ? 2 : 0], m.bufAct, m.bufG1, mi, nj, tg, lane)); }
+    else { CB_DGRAD(dgrad_layer<T, 2, 1>(m.bufG1, m.bufG0, m.bufG0, m.bufAct, m.wts + 2 * WL_BYTES, koff, w8, li, q)); }
+    CPH(PB + 8);
     __syncthreads();
+    CPH(PB + 9);
     act_store<3>(m.bufAct, pre, tid);
+    CPH(PB + 10);
     __syncthreads();
+    CPH(PB + 11);
     // ---------------------------------------------------------------- S3: layer 2 (input relu(r1), output gradient d a2)
     act_load<3>(pre, p.act[0], p.ld_act[0], b, y0, x0, H, W, tid);          // a1 for S4
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[WROLE ? 1 : 0], m.bufAct, m.bufG0, mi, nj, lane)); }
-    else { CB_DGRAD(dgrad_layer<T, 3, 0>(m.bufG0, m.bufG1, nullptr, m.bufAct, m.wts + WL_BYTES, koff, w4, li, q)); }
+    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[WROLE ? 1 : 0], m.bufAct, m.bufG0, mi, nj, tg, lane)); }
+    else { CB_DGRAD(dgrad_layer<T, 3, 0>(m.bufG0, m.bufG1, nullptr, m.bufAct, m.wts + WL_BYTES, koff, w8, li, q)); }
+    CPH(PB + 12);
     __syncthreads();
+    CPH(PB + 13);
     act_store<3>(m.bufAct, pre, tid);
+    CPH(PB + 14);
     __syncthreads();
+    CPH(PB + 15);
     // ---------------------------------------------------------------- S4: layer 1 (input a1, output gradient dc1) -> dz1 on the interior
     act_load<4>(pre, p.act[4], p.ld_act[4], b, y0, x0, H, W, tid);          // a3 (interior only) for the last 1x1 layer's weight gradient
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[0], m.bufAct, m.bufG1, mi, nj, lane)); }
-    else { CB_DGRAD(dgrad_layer<T, 4, 2>(m.bufG1, m.bufG0, m.bufG0, m.bufAct, m.wts, koff, w4, li, q)); }
+    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[0], m.bufAct, m.bufG1, mi, nj, tg, lane)); }
+    else { CB_DGRAD(dgrad_layer<T, 4, 2>(m.bufG1, m.bufG0, m.bufG0, m.bufAct, m.wts, koff, w8, li, q)); }
+    CPH(PB + 16);
     __syncthreads();
+    CPH(PB + 17);
 
     // ---------------------------------------------------------------- S5: first 1x1 layer + blend: d fine, d small, dW1, dW6
     act_store<4>(m.bufAct, pre, tid);
+    __syncthreads();                                          // a3 has landed in the activation buffer; the two parts of S5 run side by side
+    CPH(PB + 18);
 #ifndef CB_EXP_NO_S5
-    const int n24 = tid % 24, row0 = tid / 24;
-    if (!WROLE) {                                             // threads 0..255: one interior pixel each
+    const int n24 = (tid - 256) % 24, row0 = (tid - 256) / 24;      // threads 256..639: channel n24, interior row row0 (0..15)
+    if (!WROLE && tid < 256) {                                // threads 0..255: one interior pixel each
       const int bq = tid >> 2, sub = tid & 3;                 // a 2x2 block = 4 consecutive lanes
       const int y = 2 * (bq >> 3) + (sub >> 1), x = 2 * (bq & 7) + (sub & 1);
       const int pi = y * 16 + x;
-      const uint4* zp = reinterpret_cast<const uint4*>(m.bufG0 + ((4 + y) * FR + 4 + x) * PIXB);
-      float dz[24];
+      const T* zp = reinterpret_cast<const T*>(m.bufG0 + ((4 + y) * FR + 4 + x) * PIXB);
+      float dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int n4 = 0; n4 < 6; ++n4) {                        // four channels of dz1 at a time: this role has 128 registers
+        float dz[4];
+        load4<T>(zp + n4 * 4, dz);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        float v[8];
-        unpack8t<T>(zp[s], v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dz[s * 8 + e] = v[e];
-      }
-      float dx[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        float a = 0.f;
-#pragma unroll
-        for (int n4 = 0; n4 < 6; ++n4) {
+        for (int k = 0; k < 6; ++k) {
           const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(m.w_in + k * 24 + n4 * 4);
-          a += wv[0] * dz[n4 * 4] + wv[1] * dz[n4 * 4 + 1] + wv[2] * dz[n4 * 4 + 2] + wv[3] * dz[n4 * 4 + 3];
+          dx[k] += wv[0] * dz[0] + wv[1] * dz[1] + wv[2] * dz[2] + wv[3] * dz[3];
         }
-        dx[k] = Elem<T>::to_f32(Elem<T>::from_f32(a));        // the layer-wise path stores d(net input) in the storage type
-        __builtin_amdgcn_sched_barrier(0);                    // (keeps hipcc from hoisting all 36 weight vectors: 144 registers)
       }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dx[k] = Elem<T>::to_f32(Elem<T>::from_f32(dx[k]));      // the layer-wise path stores d(net input) in the storage type
       const float4 gw = *reinterpret_cast<const float4*>(m.stash_gw + pi * 4);
       const float g3[3] = {gw.x, gw.y, gw.z};
       const int gy = y0 + y, gx = x0 + x;
@@ -616,29 +704,26 @@ __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, 
         }
       }
     }
-    __syncthreads();                                          // a3 has landed in the activation buffer
-    if (!WROLE && tid < 192) {                                // the two 1x1 layers' weight gradients: channel n24, interior rows row0 and row0 + 8
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        const int row = row0 + 8 * h;
-        const char* zrow = m.bufG0 + ((4 + row) * FR + 4) * PIXB;
-        const char* arow = m.bufAct + ((4 + row) * FR + 4) * PIXB;
+    if (tid >= 256 && tid < 640) {                            // the two 1x1 layers' weight gradients, one (channel, interior row) per thread
+      const char* zrow = m.bufG0 + ((4 + row0) * FR + 4) * PIXB;
+      const char* arow = m.bufAct + ((4 + row0) * FR + 4) * PIXB;
 #pragma unroll 4
-        for (int x = 0; x < 16; ++x) {
-          const float d = Elem<T>::to_f32(reinterpret_cast<const T*>(zrow + x * PIXB)[n24]);
-          const float a3 = Elem<T>::to_f32(reinterpret_cast<const T*>(arow + x * PIXB)[n24]);
-          const float* sx = m.stash_x0 + (row * 16 + x) * 6;
+      for (int x = 0; x < 16; ++x) {
+        const float d = Elem<T>::to_f32(reinterpret_cast<const T*>(zrow + x * PIXB)[n24]);
+        const float a3 = Elem<T>::to_f32(reinterpret_cast<const T*>(arow + x * PIXB)[n24]);
+        const float* sx = m.stash_x0 + (row0 * 16 + x) * 6;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) acc1[k] += sx[k] * d;         // dW1[k][n] += x0[k] * dz1[n]
-          acc1[6] += d;                                             // db1[n]
-          const float dz6 = m.stash_dz6[row * 16 + x];
-          acc6 += a3 * dz6;                                         // dW6[n] += a3[n] * dz6
-          accb6 += dz6;                                             // db6 (every n carries the same sum; n == 0 flushes it)
-        }
+        for (int k = 0; k < 6; ++k) acc1[k] += sx[k] * d;         // dW1[k][n] += x0[k] * dz1[n]
+        acc1[6] += d;                                             // db1[n]
+        const float dz6 = m.stash_dz6[row0 * 16 + x];
+        acc6 += a3 * dz6;                                         // dW6[n] += a3[n] * dz6
+        accb6 += dz6;                                             // db6 (every n carries the same sum; n == 0 flushes it)
       }
     }
+    CPH(PB + 19);
 #endif
     __syncthreads();      // frames and stashes are rewritten by the next tile
+    CPH(PB + 20);
   }
 
   if (WROLE) {            // flush: one atomic per weight-gradient element per workgroup
@@ -646,12 +731,13 @@ __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, 
 #pragma unroll
     for (int l = 0; l < 4; ++l)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (co >= 24) continue;
+      for (int i = 0; i < 5; ++i) {
+        const int tap = tg * 5 + i;
+        if (co >= 24 || tap > 8) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ci = mi * 16 + q * 4 + e;
-          const float v = wacc[WROLE ? l : 0][tap][e];
+          const float v = wacc[WROLE ? l : 0][i][e];
           if (ci < 24) atomicAdd(p.dw_res[l] + (tap * 24 + ci) * 24 + co, v);
           else if (ci == 24 && tap == 4) atomicAdd(p.db_res[l] + co, v);
         }
@@ -660,7 +746,7 @@ __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(512) void compose_bwd_kernel(const ComposeBwdP p) {
+__global__ __launch_bounds__(BWD_THREADS) void compose_bwd_kernel(const ComposeBwdP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   BwdLds m;
   m.wts = smem;
@@ -675,10 +761,10 @@ __global__ __launch_bounds__(512) void compose_bwd_kernel(const ComposeBwdP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4;
   // ---- parameters: flipped / transposed 3x3 weights as the A operand of the data-gradient convs, the 1x1 weights in fp32 (rounded)
-  for (int i = tid; i < 4 * WL_BYTES / 16; i += 512) reinterpret_cast<uint4*>(m.wts)[i] = uint4{0u, 0u, 0u, 0u};
-  for (int i = tid; i < NFPB; i += 512) fp[i] = Elem<T>::to_f32(Elem<T>::from_f32(i < 144 ? p.w_in[i] : p.w_out[i - 144]));
+  for (int i = tid; i < 4 * WL_BYTES / 16; i += BWD_THREADS) reinterpret_cast<uint4*>(m.wts)[i] = uint4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < NFPB; i += BWD_THREADS) fp[i] = Elem<T>::to_f32(Elem<T>::from_f32(i < 144 ? p.w_in[i] : p.w_out[i - 144]));
   __syncthreads();
-  for (int e = tid; e < 4 * 5184; e += 512) {      // d in[ci] = sum_{tap', co} dc[p + tap' - 1][co] K[8 - tap'][ci][co]: row = ci, k-group = tap' * 3 + co / 8
+  for (int e = tid; e < 4 * 5184; e += BWD_THREADS) {      // d in[ci] = sum_{tap', co} dc[p + tap' - 1][co] K[8 - tap'][ci][co]: row = ci, k-group = tap' * 3 + co / 8
     const int l = e / 5184, rem = e - l * 5184;
     const int tap = rem / 576, ci = (rem / 24) % 24, co = rem % 24;
     const int g = (8 - tap) * 3 + (co >> 3);
@@ -698,22 +784,22 @@ __global__ __launch_bounds__(512) void compose_bwd_kernel(const ComposeBwdP p) {
   float acc1[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc6 = 0.f, accb6 = 0.f;
   // Nothing role-specific lives across the role branch: the weight-gradient role keeps 144 accumulator registers for the whole launch,
   // the data-gradient role its 56 weight-fragment registers per layer -- together they would not fit a wave's 256.
-  if (wave < 4) bwd_role<T, false>(p, m, koff, acc1, acc6, accb6);
+  if (wave < 8) bwd_role<T, false>(p, m, koff, acc1, acc6, accb6);
   else bwd_role<T, true>(p, m, koff, acc1, acc6, accb6);
 
   float* red = reinterpret_cast<float*>(smem);               // [row pair][n][9]: the weight images are no longer needed
   __syncthreads();
-  if (tid < 192) {
+  if (tid >= 256 && tid < 640) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) red[tid * 9 + k] = acc1[k];
-    red[tid * 9 + 7] = acc6;
-    red[tid * 9 + 8] = accb6;
+    for (int k = 0; k < 7; ++k) red[(tid - 256) * 9 + k] = acc1[k];
+    red[(tid - 256) * 9 + 7] = acc6;
+    red[(tid - 256) * 9 + 8] = accb6;
   }
   __syncthreads();
   if (tid < 24 * 9) {
     const int n = tid / 9, k = tid - n * 9;
     float s = 0.f;
-    for (int r = 0; r < 8; ++r) s += red[(r * 24 + n) * 9 + k];
+    for (int r = 0; r < 16; ++r) s += red[(r * 24 + n) * 9 + k];
     if (k < 6) atomicAdd(p.dw_in + k * 24 + n, s);
     else if (k == 6) atomicAdd(p.db_in + n, s);
     else if (k == 7) atomicAdd(p.dw_out + n, s);
@@ -797,11 +883,11 @@ extern "C" int dd_compose_net_bwd(const dd_compose_bwd_args* a, dd_stream stream
   if (a->dtype == DD_BF16) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    hipLaunchKernelGGL(compose_bwd_kernel<bf16_t>, dim3(grid), dim3(512), LDS_BWD, s, p);
+    hipLaunchKernelGGL(compose_bwd_kernel<bf16_t>, dim3(grid), dim3(BWD_THREADS), LDS_BWD, s, p);
   } else {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_bwd_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    hipLaunchKernelGGL(compose_bwd_kernel<f16_t>, dim3(grid), dim3(512), LDS_BWD, s, p);
+    hipLaunchKernelGGL(compose_bwd_kernel<f16_t>, dim3(grid), dim3(BWD_THREADS), LDS_BWD, s, p);
   }
   DD_LAUNCH_CHECK();
   return DD_OK;
