@@ -22,7 +22,7 @@ SYMBOLS = (
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
-    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd",
+    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_assemble_input",
 )
 
 
@@ -59,6 +59,11 @@ class FeatureParams(C.Structure):
 class GatherEntry(C.Structure):
     _fields_ = [("src", C.c_void_p), ("pixel_stride", C.c_int), ("batch_stride_pixels", C.c_int),
                 ("nch", C.c_int), ("dst_ch", C.c_int)]
+
+
+class AssembleEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("cs", C.c_int), ("kind", C.c_int), ("fp", FeatureParams), ("nch", C.c_int), ("dst_ch", C.c_int),
+                ("std_out", C.c_void_p), ("ld_std", C.c_int)]
 
 
 class LossDesc(C.Structure):
@@ -178,6 +183,7 @@ def load():
     lib.dd_extract_tiles.argtypes = [vp, i, i, i, i, vp, i, i, vp, i, vp]
     lib.dd_compose_net_fwd.argtypes = [C.POINTER(ComposeArgs), vp]
     lib.dd_compose_net_bwd.argtypes = [C.POINTER(ComposeBwdArgs), vp]
+    lib.dd_assemble_input.argtypes = [vp, i, i, vp, i, i, i, i, i, i, vp]
     lib.dd_kpcn_head_fwd.argtypes = [C.POINTER(HeadArgs), vp]
     lib.dd_kpcn_head_bwd.argtypes = [C.POINTER(HeadArgs), vp]
     _lib = lib

@@ -412,6 +412,121 @@ extern "C" int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n
   return DD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ fused input assembly
+// dd_prepare_feature (one launch per render pass, fp32 staging planes) + dd_gather_input (one more pass over them) as ONE launch: a workgroup
+// owns a 16x16 tile of one (tuple, tile) image and walks the tuple's entry table -- per feature entry the 18x18 haloed source tile is staged
+// and standardised in LDS, the local variance taken from it, and the entry's channels written into an LDS image of the network-input tile,
+// which finally leaves as coalesced 16-byte vectors.  HBM sees the raw passes once (12 B per pixel and pass) and the network input once
+// (c_pad storage elements per pixel); the staging planes (16 B written + 16 B read per pixel and pass) are gone, except the standardised
+// source of the passes the kernel-prediction head filters (std_out != NULL), which it needs anyway.
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_entry* __restrict__ table, int n_entries, T* __restrict__ dst, int ld, int c_pad,
+                                                             int B, int H, int W, int tiles_x, int tiles_y) {
+  constexpr int TP = 16, HP = TP + 2;
+  __shared__ float s_std[3][HP][HP + 1];
+  __shared__ float s_var[3][HP][HP + 1];
+  extern __shared__ __attribute__((aligned(16))) char s_out_raw[];      // [256 pixels][c_pad] of T
+  T* s_out = reinterpret_cast<T*>(s_out_raw);
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int b = bid % B, t = bid / B;
+  const int y0 = ty * TP, x0 = tx * TP;
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  const int y = y0 + ly, x = x0 + lx;
+  const bool live = y < H && x < W;
+  const long pix = ((long)b * H + (live ? y : 0)) * W + (live ? x : 0);
+  T* mine = s_out + threadIdx.x * c_pad;
+  for (int c = 0; c < c_pad; ++c) mine[c] = Elem<T>::from_f32(0.f);
+  for (int e = 0; e < n_entries; ++e) {
+    const dd_assemble_entry en = table[t * n_entries + e];       // block-uniform
+    if (en.nch <= 0) continue;
+    if (en.kind == 1) {                                           // a vector broadcast over the tile (the tuple's embedding row)
+      for (int c = 0; c < en.nch; ++c) mine[en.dst_ch + c] = Elem<T>::from_f32(en.src[c]);
+      continue;
+    }
+    if (en.kind == 2) {                                           // a plane copied as it is (one-hot feature flags)
+      const float* sp = en.src + pix * en.nch;
+      for (int c = 0; c < en.nch; ++c) mine[en.dst_ch + c] = Elem<T>::from_f32(sp[c]);
+      continue;
+    }
+    const dd_feature_params fp = en.fp;
+    const int cs = en.cs;
+    const float* img = en.src + (long)b * H * W * cs;
+    __syncthreads();                                              // the previous entry's staging tiles are consumed
+    for (int k = threadIdx.x; k < HP * HP; k += 256) {
+      const int py = k / HP, px = k - py * HP;
+      const int gy = sym_index(min(y0 - 1 + py, H), H), gx = sym_index(min(x0 - 1 + px, W), W);
+      for (int c = 0; c < cs; ++c) {
+        const float v = img[((long)gy * W + gx) * cs + c];
+        const float sv = standardize(v, fp);
+        s_std[c][py][px] = sv;
+        s_var[c][py][px] = fp.variance_before ? v : sv;
+      }
+    }
+    __syncthreads();
+    float rec[6];
+    rec[0] = s_std[0][ly + 1][lx + 1];
+    rec[1] = cs == 3 ? s_std[1][ly + 1][lx + 1] : rec[0];
+    rec[2] = cs == 3 ? s_std[2][ly + 1][lx + 1] : rec[0];
+    int nv = 0;
+    if (fp.use_variance) {
+      float var_acc = 0.f;
+      for (int c = 0; c < cs; ++c) {
+        float sum = 0.f, sumsq = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+          for (int bb = -1; bb <= 1; ++bb) {
+            if (fp.mode_neighbor && a != 0 && bb != 0) continue;
+            const float v = s_var[c][ly + 1 + a][lx + 1 + bb];
+            sum += v; sumsq += v * v; ++cnt;
+          }
+        const float mean = sum / cnt, meansq = sumsq / cnt;
+        float var = meansq - mean * mean;
+        if (fp.relative) var = var / fmaxf(mean * mean, fp.epsilon);
+        if (fp.compress) var_acc += var; else rec[3 + c] = var;
+      }
+      if (fp.compress) { rec[3] = var_acc / cs; nv = 1; } else nv = cs;
+    }
+    for (int c = 0; c < 3 + nv && c < en.nch; ++c) mine[en.dst_ch + c] = Elem<T>::from_f32(rec[c]);
+    if (en.std_out && live) {
+      float* so = en.std_out + pix * en.ld_std;
+      for (int c = 0; c < 3 + nv && c < en.ld_std; ++c) so[c] = rec[c];
+    }
+  }
+  __syncthreads();
+  // the tile leaves as 16-byte vectors: pixel row = c_pad elements
+  constexpr int N = Elem<T>::PER16;
+  const int vpp = c_pad / N;                                      // vectors per pixel
+  T* img_out = dst + ((long)(t * B + b) * H) * W * ld;
+  for (int v = threadIdx.x; v < 256 * vpp; v += 256) {
+    const int p = v / vpp, k = v - p * vpp;
+    const int py = p >> 4, px = p & 15;
+    if (y0 + py < H && x0 + px < W)
+      *reinterpret_cast<uint4*>(img_out + ((long)(y0 + py) * W + x0 + px) * ld + k * N) = *reinterpret_cast<const uint4*>(s_out + p * c_pad + k * N);
+  }
+}
+extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                                 int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(table && dst && n_tuples > 0 && n_entries > 0 && c_pad > 0 && c_pad <= ld, "dd_assemble_input: bad arguments");
+  DD_REQUIRE(dd_dtype_ok(dtype), "dd_assemble_input: bad dtype %d", dtype);
+  const int per16 = dtype == DD_F32 ? 4 : 8, esz = dtype == DD_F32 ? 4 : 2;
+  DD_REQUIRE(c_pad % per16 == 0 && ld % per16 == 0 && ((uintptr_t)dst % 16) == 0, "dd_assemble_input: c_pad=%d and ld=%d must be multiples of %d", c_pad, ld, per16);
+  const size_t lds = (size_t)256 * c_pad * esz;
+  DD_REQUIRE(lds <= 96 * 1024, "dd_assemble_input: %d input channels do not fit the LDS tile", c_pad);
+  const int tiles_x = dd_ceil_div(W, 16), tiles_y = dd_ceil_div(H, 16);
+  const unsigned grid = (unsigned)((long)n_tuples * B * tiles_x * tiles_y);
+  DD_DISPATCH_DTYPE(dtype, T, {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_input_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
+    hipLaunchKernelGGL(assemble_input_kernel<T>, dim3(grid), dim3(256), lds, S(stream), table, n_entries, (T*)dst, ld, c_pad, B, H, W, tiles_x, tiles_y);
+  });
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ kernel prediction
 template <typename T, int KS, bool VEC>
 __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,

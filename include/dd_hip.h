@@ -124,6 +124,15 @@ typedef struct { const float* src; int pixel_stride; int batch_stride_pixels; in
 int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
                     int B, int H, int W, int dtype, dd_stream stream);
 
+/* prepare + gather in ONE launch (bf16 / fp16 / f32): every entry of a tuple is computed from the raw pass and written straight into the
+ * network input; no fp32 staging plane.  kind 0: a render pass (src [B,H,W,cs] fp32, standardised per `fp`, local variance appended: nch = 3 +
+ * variance channels); kind 1: a vector of nch floats broadcast over the image (the embedding row of FeatureFlags.feature_flags,
+ * FeatureFlags.py:50-69); kind 2: a plane [B,H,W,nch] copied as it is (one-hot flags).  std_out (kind 0, optional): the entry's standardised
+ * channels in fp32 [B,H,W,ld_std] -- the source KernelPredictor filters (Architecture.py:262-265). */
+typedef struct { const float* src; int cs; int kind; dd_feature_params fp; int nch; int dst_ch; float* std_out; int ld_std; } dd_assemble_entry;
+int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                      int B, int H, int W, int dtype, dd_stream stream);
+
 /* ---- kernel prediction (KernelPrediction.kernel_prediction, KernelPrediction.py:11-63): softmax over k*k logits,
  * symmetric pad, per-pixel k x k filter of the 3-channel source. */
 int dd_kpcn_fwd(const float* src, int ldsrc, const void* logits, int ldl, float* out, int ldo,
