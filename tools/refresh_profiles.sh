@@ -18,5 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_IN
   timeout 600 rocprofv3 --pmc $c -d $out/pmc_$n -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-extras --no-graph --steps 2 --warmup 1 > $out/pmc_$n.log 2>&1
   python tools/pmc_family.py $out/pmc_$n conv_igemm wgrad_dma compose_fwd compose_bwd head_fwd head_bwd > $out/pmc_$n.txt 2>&1
 done
+# the multi-process path of the bench on ONE device (two ranks, gloo transport; RCCL needs >= 2 GPUs): same code above the transport
+HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_DEVICE=0 DD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 3 --batch 32 > $out/two_ranks_one_gpu.txt 2> $out/two_ranks_one_gpu.err
 rm -rf $out/prof $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 cat $out/smoke.txt | tail -2; cut -c1-300 $out/bench.json; cat $out/pmc_*.txt; head -12 $out/kernel_stats.txt
