@@ -470,8 +470,11 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
       }
       // park this pixel's operands of the weight gradients (zero rows for pixels past the end)
       const int row = s * 16 + li;
-      const uint4 z4 = {0u, 0u, 0u, 0u};
-      uint4 hs = pa.ok ? hid : z4;
+      // (component-wise selects: `ok ? a : b` on whole uint4 structs makes hipcc select between their ADDRESSES, which put x, d logits and d hid in
+      //  scratch memory -- 6 KiB of scratch stores per 16 pixels against 2 KiB of d x, measured as WRITE_SIZE 4x the algorithmic bytes)
+      const uint32_t okm = pa.ok ? 0xffffffffu : 0u;
+      auto keep4 = [okm](const uint4& v) { return uint4{v.x & okm, v.y & okm, v.z & okm, v.w & okm}; };
+      uint4 hs = keep4(hid);
       if (pa.ok && q == (ONES >> 3)) {                 // the all-ones channel: slot ONES & 7 of k-group ONES >> 3
         constexpr int OW = (ONES & 7) >> 1, OSH = ((ONES & 7) & 1) * 16;
         const uint32_t one = (pack2<T>(1.f, 1.f) & 0xffffu) << OSH, keep = ~(0xffffu << OSH);
@@ -481,10 +484,10 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
         else hs.w = (hs.w & keep) | one;
       }
       *reinterpret_cast<uint4*>(s_hid + row * 64 + q * 16) = hs;
-      *reinterpret_cast<uint4*>(s_dl + row * 64 + q * 16) = pa.ok ? dl : z4;
-      *reinterpret_cast<uint4*>(s_dh + row * 64 + q * 16) = pa.ok ? dh : z4;
+      *reinterpret_cast<uint4*>(s_dl + row * 64 + q * 16) = keep4(dl);
+      *reinterpret_cast<uint4*>(s_dh + row * 64 + q * 16) = keep4(dh);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(s_x + row * XROW + c * 64 + q * 16) = pa.ok ? xf[c] : z4;
+      for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(s_x + row * XROW + c * 64 + q * 16) = keep4(xf[c]);
     }
 #ifndef HB_EXP_NO_WGRAD
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
