@@ -20,6 +20,21 @@
 // with ds_read_b64_tr_b16 and accumulates the gradient tiles in registers for the whole launch (bias gradients = an all-ones channel).
 #include "dd_common.h"
 
+#ifdef DD_PROFILE_PHASES
+// cycle stamps of workgroup 0, thread 0 of the backward kernel (tools/head_phases.py): slot i accumulates the cycles between stamps i-1 and i
+__device__ unsigned long long dd_hphase[16];
+#define HPH_DECL() unsigned long long hph_last = __builtin_readcyclecounter(); const bool hph_on = blockIdx.x == 0 && threadIdx.x == 0
+#define HPH(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_readcyclecounter(); if (hph_on) dd_hphase[i] += now_ - hph_last; hph_last = now_; } while (0)
+extern "C" int dd_debug_hphases(unsigned long long* out16, int reset) {
+  if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dd_hphase), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_hphase), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define HPH_DECL()
+#define HPH(i)
+#endif
+
 namespace {
 
 struct HeadP {
@@ -300,9 +315,12 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
   char* s_x = s_dh + 32 * 64;                          // [32 px][NCH * 32 channels] x
   const long wave = (long)blockIdx.x * BWD_WAVES + wv, nwaves = (long)gridDim.x * BWD_WAVES;
 
+  HPH_DECL();
   const HeadW hw = stage_head_weights<KS>(reinterpret_cast<float*>(smem), a, BWD_WAVES * 64);      // (the strips are not in use yet)
+  HPH(0);
   FwdWeights<T, KS, NCH> w;
   load_fwd_weights<T, KS, NCH>(w, hw, li, q);
+  HPH(1);
   // data-gradient operands: GEMM 3  d hid[m] = sum_n Wb[m][n] dl[n]  (row m = j*16 + li, k-slot -> n = slot_ch)
   //                         GEMM 4  d x[c]   = sum_m Wa[c][m] dh[m]  (row c = ct*16 + li, k-slot -> m = slot_ch)
   uint4 a3[NT], a4[CT];
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
     for (int ct = 0; ct < CT; ++ct) s_a4[ct * 64] = a4[ct];
   }
   __syncthreads();                                     // every wave has its fragments: the staged weights give way to the strips
+  HPH(2);
   // weight-gradient tiles, kept for the whole launch (rows / columns of the K-sized dimensions are slot POSITIONS, mapped back at the end)
   // (a 32-slot row always spans NPT = 2 position tiles: with one channel tile (3x3 kernels) the valid slots e < 4 of all four k-groups
   //  still land in both halves of the row)
@@ -377,6 +396,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
     const PixelAddr p0 = seg_pixel(sw, li, a);
     load_x<T, NCH>(xnext, a, (p0.b * a.H + p0.y) * a.W + p0.x, q);
   }
+  HPH(3);
   while (sw.left > 0) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -518,34 +538,41 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
 #endif
   }
 
-  // flush.  Thousands of waves adding into the same few thousand addresses serialise in the L2 atomic units (measured: ~300 us per launch
-  // with one flush per wave), so the four waves of a workgroup first sum their tiles in LDS and wave 0 issues the global atomics.
+  // flush.  Thousands of waves adding into the same few thousand addresses serialise in the atomic units (measured: ~300 us per launch with
+  // one flush per wave), so the waves of a workgroup first sum their tiles through LDS and ONE set of global atomics leaves per workgroup.
+  // The sum is a register tree (upper half parks its tiles, lower half adds them: log2(waves) rounds of plain 16-byte stores and loads);
+  // LDS float atomics for the same job (ds_add_f32 from 8 waves into one image) took 87-136 k cycles per launch, 40 % of the small launches.
   // D tile (i, j): a lane holds rows i*16 + q*4 + e, column j*16 + li.
-  __syncthreads();                                     // every wave is done with its strip: the LDS is reused as [tile][256] fp32
-  float* red = reinterpret_cast<float*>(smem);
+  HPH(4);
+  __syncthreads();                                     // every wave is done with its strip: the LDS is reused as [wave][tile][lane] x 16 bytes
+  HPH(5);
   constexpr int NTILES = NPT * NPT + NPT + CT * NPT;
-  for (int i = threadIdx.x; i < NTILES * 256; i += BWD_WAVES * 64) red[i] = 0.f;
-  __syncthreads();
-  {
+  static_assert((BWD_WAVES / 2) * NTILES * 1024 <= BWD_WAVES * STRIP, "the parked tiles must fit the strips");
+  f32x4_t* red4 = reinterpret_cast<f32x4_t*>(smem);
+  auto each_tile = [&](auto&& f) {
     int t = 0;
 #pragma unroll
     for (int i = 0; i < NPT; ++i)
 #pragma unroll
-      for (int j = 0; j < NPT; ++j, ++t)
+      for (int j = 0; j < NPT; ++j, ++t) f(t, g_wb[i][j]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(red + t * 256 + e * 64 + lane, g_wb[i][j][e]);
-#pragma unroll
-    for (int j = 0; j < NPT; ++j, ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(red + t * 256 + e * 64 + lane, g_ba[j][e]);
+    for (int j = 0; j < NPT; ++j, ++t) f(t, g_ba[j]);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int j = 0; j < NPT; ++j, ++t)
+      for (int j = 0; j < NPT; ++j, ++t) f(t, g_wa[ct][j]);
+  };
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(red + t * 256 + e * 64 + lane, g_wa[ct][j][e]);
+  for (int half = BWD_WAVES >> 1; half >= 1; half >>= 1) {
+    if (wv >= half && wv < 2 * half) each_tile([&](int t, f32x4_t& g) { red4[((wv - half) * NTILES + t) * 64 + lane] = g; });
+    __syncthreads();
+    if (wv < half) each_tile([&](int t, f32x4_t& g) { const f32x4_t o = red4[(wv * NTILES + t) * 64 + lane]; g[0] += o[0]; g[1] += o[1]; g[2] += o[2]; g[3] += o[3]; });
+    __syncthreads();
   }
+  if (wv == 0) each_tile([&](int t, f32x4_t& g) { red4[t * 64 + lane] = g; });
   __syncthreads();
+  HPH(6);
+  const float* red = reinterpret_cast<const float*>(smem);          // element e of lane l of tile t: red[t * 256 + l * 4 + e]
   // 256 threads walk the summed tiles: thread -> (element e, lane) of a tile, exactly the layout above
   const int fl = threadIdx.x & 63, fe = threadIdx.x >> 6, fli = fl & 15, fq = fl >> 4;
 #ifndef HB_EXP_NO_FLUSH
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
       for (int j = 0; j < NPT; ++j, ++t) {
         const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = i * 16 + fq * 4 + fe, m = pos_ch(pos);
         const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
-        const float v = red[t * 256 + fe * 64 + fl];
+        const float v = red[t * 256 + fl * 4 + fe];
         if (!n_ok) continue;
         if (pos == ONES) atomicAdd(a.dbb + n, v);
         else if (((pos & 7) >> 2) < NT && m < K) atomicAdd(a.dwb + m * K + n, v);
@@ -563,16 +590,17 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
     for (int j = 0; j < NPT; ++j, ++t) {
       const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = (ONES >> 4) * 16 + fq * 4 + fe;
       const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
-      if (n_ok && pos == ONES) atomicAdd(a.dba + n, red[t * 256 + fe * 64 + fl]);
+      if (n_ok && pos == ONES) atomicAdd(a.dba + n, red[t * 256 + fl * 4 + fe]);
     }
     for (int ct = 0; ct < CT; ++ct)
       for (int j = 0; j < NPT; ++j, ++t) {
         const int cpos = j * 16 + fli, n = pos_ch(cpos), c = ct * 16 + fq * 4 + fe;
         const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
-        if (n_ok && c < a.C) atomicAdd(a.dwa + (long)c * K + n, red[t * 256 + fe * 64 + fl]);
+        if (n_ok && c < a.C) atomicAdd(a.dwa + (long)c * K + n, red[t * 256 + fl * 4 + fe]);
       }
   }
 #endif
+  HPH(7);
 }
 
 int g_head_cus = 0;
