@@ -1,0 +1,397 @@
+// Fused backward of a 3x3 SAME convolution on CDNA4: data gradient AND weight gradient of one layer from ONE pass over dy and x.
+//
+// Reference seam replaced: the two gradient ops TensorFlow's autodiff emits for tf.layers.conv2d (Conv2DBackpropInput and
+// Conv2DBackpropFilter, reached from Training.py:701-702 through UNet.py:38-48 / Architecture.py:343-420), plus the ReluGrad that follows the
+// data gradient and the BiasAddGrad of the layer.
+//
+//   dx[p][ci]       = (x[p][ci] > 0) * sum_{t, co} Wd[t][ci][co] * dy[p + off(t)][co]            (+= an existing gradient when the tensor has two consumers)
+//   dW[t][ci][co]   = sum_p x[p + off(t)][ci] * dy[p][co]  =  sum_q x[q][ci] * dy[q - off(t)][co]
+//   db[co]          = sum_p dy[p][co]
+//
+// The layer-by-layer path runs these as two launches (csrc/dd_conv_igemm.hip on dy, csrc/dd_conv_wgrad.hip): dy is fetched twice and x twice
+// (once as the ReLU mask of dx, once as the weight-gradient operand) -- 5 activation-sized HBM transfers where 3 are needed, and both launches
+// sit on the memory roof.  In the second form of dW above BOTH gradients need the same two LDS images of a 16x16 pixel tile: dy with a 1-pixel
+// halo (18x18) and x without one.  So a workgroup fetches each tile once:
+//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4, double buffered, 8 pixels x 128 bytes per wave-instruction, swizzled on the linear pixel
+//     index) -- no registers, no I/O role: the next tile streams in while this one is multiplied;
+//   * waves 0-3 (one per 16 input channels) compute dx^T = Wd * dy^T with the WEIGHTS as the register-resident A operand (18 fragments) and
+//     the dy pixels as B, walking the 18 haloed rows once: a row's fragment feeds the three output rows it touches, an output row is complete
+//     two haloed rows later and is masked with x (read from the LDS image), rounded and stored straight from the accumulators;
+//   * waves 4-7 (one per 16 output channels) accumulate dW for the whole launch in registers (9 taps x 4 input-channel tiles = 144
+//     accumulators), both operands read transposed (ds_read_b64_tr_b16: the reduction runs over pixels), and db from the centre-tap fragments;
+//     one set of fp32 atomics per workgroup at the end.
+// A SIMD hosts one wave of each role: 576 MFMAs per tile and SIMD.  Channels: C_out <= 64 (one 128-byte LDS row per pixel), C_in in blocks of
+// 64 (one workgroup column per block; dy is re-read per block).
+#include "dd_common.h"
+
+namespace {
+
+struct BwdP {
+  const void* dy; const void* x; const void* wd; void* dx; float* dw; float* db;
+  int lddy, ldx, lddx;
+  int cout, cin, coutv, cinv;      // logical / staged (rounded up to 8) channel counts
+  int n_pad, k_pad;                // packed data-gradient weights [9][n_pad (ci)][k_pad (co)]
+  int B, H, W, tiles_x, tiles_y;
+  int nblk, ksplit;                // 64-channel blocks of C_in; workgroups per block
+  int use_mask, accumulate;
+};
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+
+constexpr int BW_PW = DD_TILE + 2;                                   // haloed tile width
+constexpr int BW_PCH = (BW_PW * BW_PW + 7) / 8;                      // 41 chunks of 8 pixels (1 KiB)
+constexpr int BW_P_BYTES = BW_PCH * 1024, BW_Q_BYTES = DD_TILE * DD_TILE * DD_LDS_ROW, BW_BUF = BW_P_BYTES + BW_Q_BYTES;
+
+__device__ __forceinline__ void bw_dma_1k(const void* gptr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory");
+}
+
+// LDS addresses are 32-bit byte offsets (kept in integers so that the swizzle XORs stay integer ops and every read is a ds_read with an
+// immediate offset; generic pointers here compiled to flat loads and 64-bit address arithmetic)
+typedef uint32_t bw_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t bw_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 bw_lds16(unsigned off) {
+  const bw_u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) bw_u32x4*>(off);
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ uint2 bw_lds8(unsigned off) {
+  const bw_u32x2 v = *reinterpret_cast<const __attribute__((address_space(3))) bw_u32x2*>(off);
+  return uint2{v[0], v[1]};
+}
+__device__ __forceinline__ uint4 bw_tr_pair(unsigned a0, unsigned a1) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr_ptr>(a0));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr_ptr>(a1));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  const uint4 v = {l2.x, l2.y, h2.x, h2.y};
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  static_assert(sizeof(T) == 2, "fused conv backward: bf16 / fp16 storage");
+  constexpr int PW = BW_PW, QPC = 4, PPC = 6, NP = QPC + PPC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = blockIdx.x / a.ksplit, ks = blockIdx.x - cb * a.ksplit;
+  const bool drole = wave < 4;
+  const int wr = wave & 3;
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- LDS-DMA: this lane's part of every 1-KiB chunk = pixel r of the chunk, logical 16-byte channel slot ls
+  const int r = lane >> 3, ls = (lane & 7) ^ r;
+  const int xch = cb * 64 + ls * 8, dch = ls * 8;
+  const bool x_ok = xch < a.cinv, d_ok = dch < a.coutv;
+  const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
+  const int per_img = a.tiles_y * a.tiles_x;
+  const int total_tiles = a.B * per_img;
+  int q_off[2];                 // x tile: chunk c = wave*4 + k is tile row c >> 1, pixels (c & 1)*8 + r
+#pragma unroll
+  for (int h = 0; h < 2; ++h) q_off[h] = ((h * 8 + r) * a.ldx + xch) * 2;
+  int p_yx[PPC];                // haloed dy tile: chunk c = k*8 + wave is pixels c*8 + r of the 18x18 tile
+#pragma unroll
+  for (int k = 0; k < PPC; ++k) {
+    const int pix = (k * 8 + wave) * 8 + r;
+    const int py = (pix * 3641) >> 16, px = pix - py * PW;          // pix / 18 for pix < 400
+    p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (255 << 8);        // dummy pixels of the last chunk: always out of range
+  }
+  const int dy_row = a.W * a.lddy * 2, dy_pix = a.lddy * 2;          // bytes
+  struct Origin { const char* q; const char* p; int b, y0, x0; bool live; };
+  auto origin = [&](int tile) {
+    Origin o;
+    o.live = tile < total_tiles;
+    const int t = o.live ? tile : 0;
+    o.b = t / per_img;
+    const int rem = t - o.b * per_img, ty = rem / a.tiles_x;
+    o.y0 = ty * DD_TILE; o.x0 = (rem - ty * a.tiles_x) * DD_TILE;
+    o.q = reinterpret_cast<const char*>(X + ((long)o.b * a.H * a.W + (long)o.y0 * a.W + o.x0) * a.ldx);
+    o.p = reinterpret_cast<const char*>(DY + ((long)o.b * a.H * a.W + (long)(o.y0 - 1) * a.W + (o.x0 - 1)) * a.lddy);
+    return o;
+  };
+  auto piece = [&](int k, const Origin& o, int sel) {      // DMA piece k of the tile at `o` into buffer `sel`: k < QPC -> x chunk, else dy chunk
+    const unsigned buf = lds_base + sel * BW_BUF;
+    if (k < QPC) {
+      const int c = wave * QPC + k, row = c >> 1, h = c & 1;
+      const bool ok = o.live && x_ok && o.y0 + row < a.H && o.x0 + h * 8 + r < a.W;
+      bw_dma_1k(ok ? o.q + (long)row * a.W * a.ldx * 2 + q_off[h] : zero, buf + BW_P_BYTES + c * 1024);
+    } else {
+      const int kk = k - QPC, c = kk * 8 + wave;
+      if (c < BW_PCH) {      // wave-uniform
+        const int py = p_yx[kk] >> 8, px = p_yx[kk] & 255, gy = o.y0 - 1 + py, gx = o.x0 - 1 + px;
+        const bool ok = o.live && d_ok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        bw_dma_1k(ok ? o.p + (py * dy_row + px * dy_pix + dch * 2) : zero, buf + c * 1024);
+      }
+    }
+  };
+
+  // (per tile: makes the piece constants opaque so that hipcc does not hoist every piece's derived coordinates and offsets out of the tile
+  //  loop -- ~20 registers that then spill, and a scratch reload next to a DMA means s_waitcnt vmcnt(0) = a full HBM round trip mid-tile)
+  auto launder = [&]() {
+#pragma unroll
+    for (int k = 0; k < PPC; ++k) asm volatile("" : "+v"(p_yx[k]));
+    asm volatile("" : "+v"(q_off[0]), "+v"(q_off[1]));
+  };
+  {
+    const Origin o0 = origin(ks);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) piece(k, o0, 0);
+  }
+
+  if (drole) {
+    // ================================================================== data-gradient role: wave = input-channel tile wr of this block
+    const int li = lane & 15, q = lane >> 4;
+    const int ci_row = cb * 64 + wr * 16 + li;                  // A rows: this lane's weight row
+    const int c4 = cb * 64 + wr * 16 + q * 4;                   // D rows: the 4 input channels this lane stores
+#ifdef CBW_EXP_NO_DROLE
+    const bool active = false;
+#else
+    const bool active = cb * 64 + wr * 16 < a.cin;
+#endif
+    uint4 wf[9][2];
+    {
+      const T* Wd = reinterpret_cast<const T*>(a.wd);
+      const T* zw = reinterpret_cast<const T*>(&dd_zero16_v);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const int k0 = kc * 32 + q * 8;
+          const bool ok = ci_row < a.n_pad && k0 < a.k_pad;
+          wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + k0 : zw);
+        }
+    }
+    int dbase[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dbase[c] = li * DD_LDS_ROW + ((q ^ ((li + c) & 7)) << 4);
+    const int mbase = li * DD_LDS_ROW + (((wr * 2 + (q >> 1)) ^ (li & 7)) << 4) + (q & 1) * 8;     // x image: pixel (row, li), channels wr*16 + q*4 ..
+    T* __restrict__ DX = reinterpret_cast<T*>(a.dx);
+    const bool ch_ok = c4 < a.cinv;
+
+    int sel = 0;
+    for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
+      __syncthreads();                      // ... and everyone's; buffer sel^1 is free
+      launder();
+      const Origin on = origin(tile + a.ksplit);
+      if (!active) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) piece(k, on, sel ^ 1);
+        continue;
+      }
+      const Origin oc = origin(tile);
+      const unsigned ptile = lds_base + sel * BW_BUF, qtile = ptile + BW_P_BYTES;
+      unsigned d0[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d0[c] = ptile + dbase[c];
+      const unsigned mrow = qtile + mbase;
+      const bool col_ok = ch_ok && oc.x0 + li < a.W;
+      T* dxp = DX + ((long)oc.b * a.H * a.W + (long)oc.y0 * a.W + oc.x0 + li) * a.lddx + c4;
+      const long row_stride = (long)a.W * a.lddx;
+      f32x4_t acc[3];
+      uint2 oldv[3], mv[3];
+#pragma unroll
+      for (int yy = 0; yy < PW; ++yy) {
+        if (yy < DD_TILE) {
+          acc[yy % 3] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          mv[yy % 3] = bw_lds8(mrow + yy * DD_TILE * DD_LDS_ROW);
+          oldv[yy % 3] = uint2{0u, 0u};
+          if (a.accumulate && col_ok && oc.y0 + yy < a.H) oldv[yy % 3] = *reinterpret_cast<const uint2*>(dxp + yy * row_stride);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          if ((k * PW) / NP == yy) piece(k, on, sel ^ 1);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            const int C = yy * PW + dx;      // (layers with <= 32 output channels multiply zeros for kc = 1: rare and small)
+            const uint4 f = bw_lds16((d0[C & 7] ^ (kc << 6)) + C * DD_LDS_ROW);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              const int y = yy - dy;
+              if (y >= 0 && y < DD_TILE) acc[y % 3] = mma16<T>(wf[dy * 3 + dx][kc], f, acc[y % 3]);
+            }
+          }
+        if (yy >= 2) {      // output row y = yy - 2 is complete
+          const int y = yy - 2;
+          const f32x4_t v = acc[y % 3];
+          uint2 o2;
+          o2.x = pack2<T>(v[0], v[1]);
+          o2.y = pack2<T>(v[2], v[3]);
+          if (a.use_mask) { o2.x = mask_bf16x2(o2.x, mv[y % 3].x); o2.y = mask_bf16x2(o2.y, mv[y % 3].y); }
+          if (a.accumulate) {
+            float f8[8], g8[8];
+            unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
+            unpack8t<T>(uint4{oldv[y % 3].x, oldv[y % 3].y, 0u, 0u}, g8);
+            o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
+            o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+          }
+          if (col_ok && oc.y0 + y < a.H) *reinterpret_cast<uint2*>(dxp + y * row_stride) = o2;
+        }
+      }
+    }
+  } else {
+    // ================================================================== weight-gradient role: wave = output-channel tile wr
+    const int li = lane & 15, q4 = (lane >> 4) * 4;
+#ifdef CBW_EXP_NO_WROLE
+    const bool active = false;
+#else
+    const bool active = wr * 16 < a.cout;
+#endif
+    const bool bias_wave = a.db != nullptr && cb == 0;
+    const int nci = min(4, (a.cin - cb * 64 + 15) >> 4);        // input-channel tiles of this block that exist
+    // Fragment addresses (32-bit LDS offsets).  A lane's pixel for a transposed read at tile position C (= row*PW + dx, a compile-time
+    // constant) is pl + C, so its address is  tile + [pl*128 + ((slot ^ ((pl + (C & 7)) & 7)) << 4) + half] + C*128 : eight lane-dependent
+    // bases plus an immediate.  The bases hold the CURRENT buffer's addresses and flip by +-BW_BUF per tile (no second copy kept).
+    unsigned pb[8], qb[2];
+    {
+      const int t16 = lane & 15, gq = lane >> 4, sub = t16 & 3;
+      const int yl = gq >> 1, xl = (gq & 1) * 8 + (t16 >> 2), halfb = (sub & 1) * 8;
+      const int pl = yl * PW + xl, ql = yl * DD_TILE + xl;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pb[c] = lds_base + pl * DD_LDS_ROW + (((wr * 2 + (sub >> 1)) ^ ((pl + c) & 7)) << 4) + halfb;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)      // input-channel tile 0; tile i: ^ (i << 5)
+        qb[h] = lds_base + BW_P_BYTES + ql * DD_LDS_ROW + (((sub >> 1) ^ ((ql + 4 * h) & 7)) << 4) + halfb;
+    }
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    auto x_frag = [&](int s, int i) {      // x^T: rows 2s, 2s+1 of the tile, input-channel tile i
+      return bw_tr_pair((qb[0] ^ (i << 5)) + (2 * s * DD_TILE) * DD_LDS_ROW, (qb[1] ^ (i << 5)) + (2 * s * DD_TILE + 4) * DD_LDS_ROW);
+    };
+    auto dy_frag = [&](int step) {         // dy^T shifted by tap t = step % 9, rows 2s, 2s+1 (s = step / 9)
+      const int s = step / 9, t = step - 9 * s;
+      const int c0 = (2 * s + t / 3) * PW + t % 3;
+      return bw_tr_pair(pb[c0 & 7] + c0 * DD_LDS_ROW, pb[(c0 + 4) & 7] + (c0 + 4) * DD_LDS_ROW);
+    };
+
+    int sel = 0;
+    for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      launder();
+      const Origin on = origin(tile + a.ksplit);
+      if (!active) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) piece(k, on, sel ^ 1);
+        continue;
+      }
+      // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each; the dy fragment of step n+1 and (during taps 4..7) the x fragments of the next
+      // row pair are requested before the MFMAs of step n.  sched_barriers keep hipcc from hoisting a whole row pair's 26 reads (52 registers).
+      uint4 xf[2][4], df[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[0][i] = x_frag(0, i);
+      df[0] = dy_frag(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int step = s * 9 + t;
+        if (step + 1 < 72) df[(step + 1) & 1] = dy_frag(step + 1);
+        if (s + 1 < 8 && t >= 4 && t < 8) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          if ((k * 72) / NP == step) piece(k, on, sel ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = mma16<T>(xf[s & 1][i], df[step & 1], acc[t][i]);
+        if (t == 4 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel wr*16 + li per lane
+          float f[8];
+          unpack8t<T>(df[step & 1], f);
+          bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the other buffer next time
+      const int flip = sel ? -BW_BUF : BW_BUF;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pb[c] += flip;
+      qb[0] += flip; qb[1] += flip;
+    }
+
+    // flush: D[t][i] rows = input channels i*16 + q4 + e, column = output channel wr*16 + li; shifted-dy tap t is TensorFlow's tap 8 - t
+    if (active) {
+      const int co = wr * 16 + li;
+      if (co < a.cout) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i >= nci) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ci = cb * 64 + i * 16 + q4 + e;
+              if (ci < a.cin) atomicAdd(a.dw + ((long)(8 - t) * a.cin + ci) * a.cout + co, acc[t][i][e]);
+            }
+          }
+      }
+      if (bias_wave) {
+        float b = bsum;
+        b += __shfl_xor(b, 16);
+        b += __shfl_xor(b, 32);
+        if (lane < 16 && co < a.cout) atomicAdd(a.db + co, b);
+      }
+    }
+  }
+}
+
+static int bwd_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename T>
+int launch_bwd(BwdP& p, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)BW_BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long blocks = (long)p.nblk * p.ksplit;
+  hipLaunchKernelGGL((conv_bwd_kernel<T>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+}  // namespace
+
+extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
+  DD_REQUIRE(a && a->dy && a->x && a->wd && a->dx && a->dw, "dd_conv3x3_bwd: null pointer");
+  DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_bwd: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm + dd_conv_wgrad)", a->dtype);
+  DD_REQUIRE(a->cout > 0 && a->cout <= 64 && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d (cout <= 64)", a->cout, a->cin);
+  const int coutv = (a->cout + 7) / 8 * 8, cinv = (a->cin + 7) / 8 * 8;
+  DD_REQUIRE(a->ld_dy % 8 == 0 && a->ld_x % 8 == 0 && a->ld_dx % 4 == 0 && coutv <= a->ld_dy && cinv <= a->ld_x && cinv <= a->ld_dx,
+             "dd_conv3x3_bwd: ld_dy=%d ld_x=%d ld_dx=%d must cover the channel counts rounded to 8 (ld_dy, ld_x multiples of 8)", a->ld_dy, a->ld_x, a->ld_dx);
+  DD_REQUIRE(((uintptr_t)a->dy % 16) == 0 && ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wd % 16) == 0 && ((uintptr_t)a->dx % 8) == 0,
+             "dd_conv3x3_bwd: dy / x / wd must be 16-byte aligned, dx 8-byte aligned");
+  DD_REQUIRE(a->n_pad >= a->cin && a->k_pad >= a->cout && a->k_pad % 8 == 0, "dd_conv3x3_bwd: packed weights [9][n_pad=%d][k_pad=%d] do not cover %d x %d", a->n_pad, a->k_pad, a->cin, a->cout);
+  DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && (long)a->B * a->H * a->W < (1L << 31) / 256, "dd_conv3x3_bwd: empty or oversized grid");
+  BwdP p;
+  p.dy = a->dy; p.x = a->x; p.wd = a->wd; p.dx = a->dx; p.dw = a->dw; p.db = a->db;
+  p.lddy = a->ld_dy; p.ldx = a->ld_x; p.lddx = a->ld_dx;
+  p.cout = a->cout; p.cin = a->cin; p.coutv = coutv; p.cinv = cinv;
+  p.n_pad = a->n_pad; p.k_pad = a->k_pad;
+  p.B = a->B; p.H = a->H; p.W = a->W;
+  p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
+  p.nblk = dd_ceil_div(a->cin, 64);
+  const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
+  long ksplit = bwd_cus() / p.nblk;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > total_tiles) ksplit = total_tiles;
+  p.ksplit = (int)ksplit;
+  p.use_mask = a->use_mask; p.accumulate = a->accumulate;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == DD_BF16) return launch_bwd<bf16_t>(p, s);
+  return launch_bwd<f16_t>(p, s);
+}

@@ -212,7 +212,7 @@ class Graph:
         self.layers = {}
         self.keep = []     # keeps auxiliary device buffers alive
         self.zero_init_buffers = []     # gradient buffers with several partial-range writers: zeroed before every backward pass
-        self.conv_records, self.wgrad_records = [], []
+        self.conv_records, self.wgrad_records, self.bwd_records = [], [], []
         self._pack_records = []
 
     # ------------------------------------------------------------------ weight packing: every layer in ONE launch
@@ -308,6 +308,28 @@ class Graph:
         run.info = self.wgrad_records[-1]
         return run
 
+    def _conv_bwd_call(self, gy, x, layer, wd, n_pad, k_pad, gx, use_mask, accumulate):
+        """Data + weight + bias gradients of a 3x3 layer in one launch (csrc/dd_conv_bwd.hip)."""
+        B, H, W = x.B, x.H, x.W
+        self.bwd_records.append({"flops": 4.0 * B * H * W * 9 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 9, "n": layer.cin, "k": layer.cout,
+                                 "accumulate": bool(accumulate)})
+        ps = self.params
+        a = L.ConvBwdArgs()
+        a.dy, a.ld_dy, a.cout = gy.ptr, gy.ld, layer.cout
+        a.x, a.ld_x, a.cin = x.ptr, x.ld, layer.cin
+        a.wd, a.n_pad, a.k_pad = wd.data_ptr(), n_pad, k_pad
+        a.dx, a.ld_dx = gx.ptr, gx.ld
+        a.dw, a.db = ps.grad_ptr(layer.kernel), ps.grad_ptr(layer.bias)
+        a.B, a.H, a.W = B, H, W
+        a.use_mask, a.accumulate, a.dtype = int(bool(use_mask)), int(bool(accumulate)), self.code
+        lib = self.lib
+        keep = (gy.buf, x.buf, wd, gx.buf)
+
+        def run(stream, a=a, keep=keep):
+            L.check(lib.dd_conv3x3_bwd(C.byref(a), stream))
+        run.info = self.bwd_records[-1]
+        return run
+
     def _bias_grad_call(self, gy, cout, bias_param):
         lib, code, ps = self.lib, self.code, self.params
 
@@ -351,6 +373,18 @@ class Graph:
                 return
             gy = y.grad()
             self._self_mask(y, gy)
+            # one pass over dy and x for both gradients (3x3, <= 64 output channels, bf16 / f16 storage): csrc/dd_conv_bwd.hip
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout <= 64 and not in_relu and x.requires_grad
+                    and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):
+                wd, _, dn_pad, dk_pad = layer.packed("dgrad")
+                gx = x.grad()
+                use_mask, accumulate = x.relu, x.grad_written
+                self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, wd, dn_pad, dk_pad, gx, use_mask, accumulate), "conv_bwd"),
+                         grad_params=[layer.kernel, layer.bias])
+                x.mark_grad_written()
+                if res is not None and res.requires_grad:
+                    self._masked_add_bwd(res, gy)
+                return
             wflags = L.IN_RELU if in_relu else 0
             self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags,
                                                           ps.grad_ptr(layer.bias), 1), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])

@@ -93,6 +93,23 @@ typedef struct {
 } dd_wgrad_args;
 int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream);
 
+/* ---- fused backward of a 3x3 SAME conv2d (stride 1): the data gradient (Conv2DBackpropInput + the ReluGrad of the layer's input) AND the
+ * weight / bias gradients (Conv2DBackpropFilter, BiasAddGrad) that TensorFlow's autodiff emits for tf.layers.conv2d (Training.py:701-702 over
+ * UNet.py:38-48), from ONE pass over dy and x (dd_conv_igemm + dd_conv_wgrad fetch each of them twice).  bf16 / f16 storage, cout <= 64.
+ *   dx[p][ci] = (use_mask ? x[p][ci] > 0 : 1) * sum_{t,co} wd[t][ci][co] * dy[p + off(t)][co]      (accumulate != 0: added to the existing dx)
+ *   dw[t][ci][co] += sum_p x[p + off(t)][ci] * dy[p][co]     (TensorFlow kernel layout [3][3][cin][cout], fp32 atomics: zero it first)
+ *   db[co] += sum_p dy[p][co]                                  (optional) */
+typedef struct {
+  const void* dy; int ld_dy; int cout; /* gradient of the layer's output [B,H,W,ld_dy]; channels up to the next multiple of 8 readable and zero */
+  const void* x; int ld_x; int cin;    /* the layer's input [B,H,W,ld_x] (weight-gradient operand and ReLU mask of dx) */
+  const void* wd; int n_pad; int k_pad;/* data-gradient weights as dd_pack_weights lays them out for dd_conv_igemm: [9][n_pad (ci)][k_pad (co)] */
+  void* dx; int ld_dx;                 /* [B,H,W,ld_dx] */
+  float* dw; float* db;                /* db may be NULL */
+  int B, H, W;
+  int use_mask; int accumulate; int dtype;
+} dd_conv_bwd_args;
+int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream);
+
 /* column sums: out[c] += sum_rows x[row*ld + c]  (bias gradients; embedding-row gradients) */
 int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream);
 

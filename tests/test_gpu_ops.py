@@ -72,6 +72,24 @@ def test_conv_fwd_bwd(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x
     _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B=2)
 
 
+# the fused data + weight gradient launch (csrc/dd_conv_bwd.hip: 3x3, <= 64 output channels, bf16 / f16 storage; f32 runs the two-launch path)
+FUSED_BWD_CASES = [
+    (64, 64, 32, 32, True, 2),        # the U-Net body layer: every wave of both roles busy
+    (64, 64, 20, 28, True, 3),        # ragged tiles
+    (128, 64, 16, 48, True, 2),       # two 64-channel input blocks (decoder conv over the skip concat)
+    (96, 48, 16, 16, True, 2),        # half input block, 3 output-channel tiles
+    (32, 64, 16, 16, False, 2),       # no ReLU mask on the input
+    (8, 16, 40, 24, True, 1),         # narrow: one tile of each kind, 32-channel K
+    (72, 40, 33, 17, True, 2),        # nothing a multiple of 16
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,x_relu,B", FUSED_BWD_CASES)
+def test_conv_fused_backward(eng, dtype, cin, cout, H, W, x_relu, B):
+    _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, x_relu, B=B, expect_fused_bwd=True)
+
+
 @pytest.mark.parametrize("k,cin,cout,H,W,B", [(1, 16, 27, 16, 32, 8), (1, 27, 27, 16, 32, 8), (3, 32, 16, 16, 32, 8), (1, 24, 1, 16, 32, 24),
                                                (3, 24, 24, 16, 32, 24), (1, 16, 27, 8, 16, 8), (3, 16, 16, 32, 16, 5), (3, 16, 16, 48, 16, 3)])
 def test_conv_non_square_batches(eng, k, cin, cout, H, W, B):
@@ -86,7 +104,7 @@ def test_conv_over_skip_concat_runs_as_two_resident_launches(eng, dtype, cin, co
     _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, split_at=split_at)
 
 
-def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None):
+def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None, expect_fused_bwd=False):
     gen = _gen(k * 1000 + cin + cout)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=True)
@@ -105,6 +123,8 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
     y.mark_grad_written()
     g.build_backward()
     g.finalize()
+    if expect_fused_bwd:
+        assert [getattr(op, "tag", "") for op in g.bwd_ops] == ["conv_bwd"], "the fused backward did not engage"
     wv = representable(torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) / (k * cin ** 0.5), dtype)
     bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
     set_param(g.params, lay.kernel, wv)
