@@ -66,80 +66,87 @@ __device__ __forceinline__ uint4 bw_tr_pair(unsigned a0, unsigned a1) {
   return v;
 }
 
-template <typename T>
+// acc += A * B with the accumulator tied to ONE register tuple (inline asm, "+v").  Through the builtin hipcc renames the 36 accumulator tuples
+// of the weight-gradient role as it goes (vDst != SrcC: 62 distinct tuples in the loop, ~100 extra registers, spills inside the MFMA stream).
+// No hazard recogniser sees inside the asm: the role's accumulators are each touched once per 36 MFMAs and read only after the tile loop
+// (behind explicit s_nops), its A / B operands are written by LDS reads only (waited for by the s_waitcnt the compiler still inserts).
+template <typename T> __device__ __forceinline__ void bw_mma_inplace(f32x4_t& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void bw_mma_inplace<bf16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
+  const bw_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+}
+template <> __device__ __forceinline__ void bw_mma_inplace<f16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
+  const bw_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+}
+
+// MASK / ACCUM are template flags, not runtime branches: a runtime `accumulate` left the (never executed) gradient load in the row loop, its
+// destination registers shared with the row pointer, and hipcc guarded that with s_waitcnt vmcnt(0) once per output row -- a wait for every DMA
+// piece in flight, i.e. an HBM round trip 16 times per tile.
+template <typename T, bool MASK, bool ACCUM>
 __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   static_assert(sizeof(T) == 2, "fused conv backward: bf16 / fp16 storage");
-  constexpr int PW = BW_PW, QPC = 4, PPC = 6, NP = QPC + PPC;
+  constexpr int PW = BW_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = blockIdx.x / a.ksplit, ks = blockIdx.x - cb * a.ksplit;
-  const bool drole = wave < 4;
   const int wr = wave & 3;
-  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-
-  // ---- LDS-DMA: this lane's part of every 1-KiB chunk = pixel r of the chunk, logical 16-byte channel slot ls
-  const int r = lane >> 3, ls = (lane & 7) ^ r;
-  const int xch = cb * 64 + ls * 8, dch = ls * 8;
-  const bool x_ok = xch < a.cinv, d_ok = dch < a.coutv;
-  const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
   const int per_img = a.tiles_y * a.tiles_x;
   const int total_tiles = a.B * per_img;
-  int q_off[2];                 // x tile: chunk c = wave*4 + k is tile row c >> 1, pixels (c & 1)*8 + r
-#pragma unroll
-  for (int h = 0; h < 2; ++h) q_off[h] = ((h * 8 + r) * a.ldx + xch) * 2;
-  int p_yx[PPC];                // haloed dy tile: chunk c = k*8 + wave is pixels c*8 + r of the 18x18 tile
-#pragma unroll
-  for (int k = 0; k < PPC; ++k) {
-    const int pix = (k * 8 + wave) * 8 + r;
-    const int py = (pix * 3641) >> 16, px = pix - py * PW;          // pix / 18 for pix < 400
-    p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (255 << 8);        // dummy pixels of the last chunk: always out of range
-  }
-  const int dy_row = a.W * a.lddy * 2, dy_pix = a.lddy * 2;          // bytes
-  struct Origin { const char* q; const char* p; int b, y0, x0; bool live; };
-  auto origin = [&](int tile) {
-    Origin o;
-    o.live = tile < total_tiles;
-    const int t = o.live ? tile : 0;
-    o.b = t / per_img;
-    const int rem = t - o.b * per_img, ty = rem / a.tiles_x;
-    o.y0 = ty * DD_TILE; o.x0 = (rem - ty * a.tiles_x) * DD_TILE;
-    o.q = reinterpret_cast<const char*>(X + ((long)o.b * a.H * a.W + (long)o.y0 * a.W + o.x0) * a.ldx);
-    o.p = reinterpret_cast<const char*>(DY + ((long)o.b * a.H * a.W + (long)(o.y0 - 1) * a.W + (o.x0 - 1)) * a.lddy);
-    return o;
-  };
-  auto piece = [&](int k, const Origin& o, int sel) {      // DMA piece k of the tile at `o` into buffer `sel`: k < QPC -> x chunk, else dy chunk
-    const unsigned buf = lds_base + sel * BW_BUF;
-    if (k < QPC) {
-      const int c = wave * QPC + k, row = c >> 1, h = c & 1;
-      const bool ok = o.live && x_ok && o.y0 + row < a.H && o.x0 + h * 8 + r < a.W;
-      bw_dma_1k(ok ? o.q + (long)row * a.W * a.ldx * 2 + q_off[h] : zero, buf + BW_P_BYTES + c * 1024);
-    } else {
-      const int kk = k - QPC, c = kk * 8 + wave;
-      if (c < BW_PCH) {      // wave-uniform
-        const int py = p_yx[kk] >> 8, px = p_yx[kk] & 255, gy = o.y0 - 1 + py, gx = o.x0 - 1 + px;
-        const bool ok = o.live && d_ok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        bw_dma_1k(ok ? o.p + (py * dy_row + px * dy_pix + dch * 2) : zero, buf + c * 1024);
-      }
-    }
-  };
 
-  // (per tile: makes the piece constants opaque so that hipcc does not hoist every piece's derived coordinates and offsets out of the tile
-  //  loop -- ~20 registers that then spill, and a scratch reload next to a DMA means s_waitcnt vmcnt(0) = a full HBM round trip mid-tile)
-  auto launder = [&]() {
-#pragma unroll
-    for (int k = 0; k < PPC; ++k) asm volatile("" : "+v"(p_yx[k]));
-    asm volatile("" : "+v"(q_off[0]), "+v"(q_off[1]));
-  };
-  {
-    const Origin o0 = origin(ks);
-#pragma unroll
-    for (int k = 0; k < NP; ++k) piece(k, o0, 0);
-  }
-
-  if (drole) {
+  if (wave < 4) {
     // ================================================================== data-gradient role: wave = input-channel tile wr of this block
+    // This role also issues ALL the LDS-DMA of the workgroup (the weight-gradient role holds 144 accumulators and has no registers for the
+    // per-lane piece coordinates; with the DMA here it has no vector-memory traffic at all).  A lane's part of a 1-KiB chunk: pixel r of the
+    // chunk, logical 16-byte channel slot ls.  x tile: chunk c = wr*8 + k (tile row c >> 1, pixels (c & 1)*8 + r); haloed dy tile: chunk
+    // c = k*4 + wr (pixels c*8 + r of the 18x18 tile in row-major order), coordinates recomputed per piece (a few VALU ops under the MFMAs).
+    constexpr int QPC = 8, PPC = (BW_PCH + 3) / 4, NP = QPC + PPC;      // 8 + 11 pieces per wave and tile
+    const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const int r = lane >> 3, ls = (lane & 7) ^ r;
+    const int xch = cb * 64 + ls * 8, dch = ls * 8;
+    const bool x_ok = xch < a.cinv, d_ok = dch < a.coutv;
+    const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
+    const int x_row = a.W * a.ldx * 2, x_lane = (r * a.ldx + xch) * 2;                  // bytes
+    const int dy_row = a.W * a.lddy * 2, dy_pix = a.lddy * 2, dy_lane = dch * 2;
+    struct Origin { const char* q; const char* p; int b, y0, x0; bool live; };
+    auto origin = [&](int tile) {
+      Origin o;
+      o.live = tile < total_tiles;
+      const int t = o.live ? tile : 0;
+      o.b = t / per_img;
+      const int rem = t - o.b * per_img, ty = rem / a.tiles_x;
+      o.y0 = ty * DD_TILE; o.x0 = (rem - ty * a.tiles_x) * DD_TILE;
+      o.q = reinterpret_cast<const char*>(X + ((long)o.b * a.H * a.W + (long)o.y0 * a.W + o.x0) * a.ldx);
+      o.p = reinterpret_cast<const char*>(DY + ((long)o.b * a.H * a.W + (long)(o.y0 - 1) * a.W + (o.x0 - 1)) * a.lddy);
+      return o;
+    };
+    auto piece = [&](int k, const Origin& o, int sel) {      // DMA piece k of the tile at `o` into buffer `sel`: k < QPC -> x chunk, else dy chunk
+      const unsigned buf = lds_base + sel * BW_BUF;
+      // (opaque copies per piece: otherwise hipcc hoists every piece's tile-invariant coordinates and offsets out of the tile loop -- ~25
+      //  registers that then spill, and a scratch reload in a wave with DMA in flight means s_waitcnt vmcnt(0) = an HBM round trip mid-tile)
+      int rr = r, xl = x_lane;
+      asm volatile("" : "+v"(rr), "+v"(xl));
+      if (k < QPC) {
+        const int c = wr * QPC + k, row = c >> 1, h = c & 1;
+        const bool ok = o.live && x_ok && o.y0 + row < a.H && o.x0 + h * 8 + rr < a.W;
+        bw_dma_1k(ok ? o.q + (row * x_row + h * 8 * a.ldx * 2 + xl) : zero, buf + BW_P_BYTES + c * 1024);
+      } else {
+        const int c = (k - QPC) * 4 + wr;
+        if (c < BW_PCH) {      // wave-uniform
+          const int pix = c * 8 + rr;
+          const int py = (pix * 3641) >> 16, px = pix - py * PW;          // pix / 18 for pix < 400
+          const int gy = o.y0 - 1 + py, gx = o.x0 - 1 + px;
+          const bool ok = o.live && d_ok && pix < PW * PW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          bw_dma_1k(ok ? o.p + (py * dy_row + px * dy_pix + dy_lane) : zero, buf + c * 1024);
+        }
+      }
+    };
+    Origin oc = origin(ks);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) piece(k, oc, 0);
+
     const int li = lane & 15, q = lane >> 4;
     const int ci_row = cb * 64 + wr * 16 + li;                  // A rows: this lane's weight row
     const int c4 = cb * 64 + wr * 16 + q * 4;                   // D rows: the 4 input channels this lane stores
@@ -161,75 +168,88 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
           wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + k0 : zw);
         }
     }
-    int dbase[8];
+    // Fragment addresses (32-bit LDS offsets of the CURRENT buffer; they flip by +-BW_BUF per tile).  dy image: pixel C + li (C = row*18 + dx,
+    // a compile-time constant), 16-byte slot kc*4 + q  ->  (C + li)*128 + ((slot ^ ((C + li) & 7)) << 4) = d0[C & 7] ^ (kc << 6), + C*128.
+    unsigned d0[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dbase[c] = li * DD_LDS_ROW + ((q ^ ((li + c) & 7)) << 4);
-    const int mbase = li * DD_LDS_ROW + (((wr * 2 + (q >> 1)) ^ (li & 7)) << 4) + (q & 1) * 8;     // x image: pixel (row, li), channels wr*16 + q*4 ..
+    for (int c = 0; c < 8; ++c) d0[c] = lds_base + li * DD_LDS_ROW + ((q ^ ((li + c) & 7)) << 4);
+    unsigned mrow = lds_base + BW_P_BYTES + li * DD_LDS_ROW + (((wr * 2 + (q >> 1)) ^ (li & 7)) << 4) + (q & 1) * 8;     // x image: pixel (row, li), channels wr*16 + q*4 ..
     T* __restrict__ DX = reinterpret_cast<T*>(a.dx);
     const bool ch_ok = c4 < a.cinv;
+    const long row_stride = (long)a.W * a.lddx;
 
     int sel = 0;
     for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
       __syncthreads();                      // ... and everyone's; buffer sel^1 is free
-      launder();
       const Origin on = origin(tile + a.ksplit);
       if (!active) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) piece(k, on, sel ^ 1);
+        oc = on;
         continue;
       }
-      const Origin oc = origin(tile);
-      const unsigned ptile = lds_base + sel * BW_BUF, qtile = ptile + BW_P_BYTES;
-      unsigned d0[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) d0[c] = ptile + dbase[c];
-      const unsigned mrow = qtile + mbase;
       const bool col_ok = ch_ok && oc.x0 + li < a.W;
       T* dxp = DX + ((long)oc.b * a.H * a.W + (long)oc.y0 * a.W + oc.x0 + li) * a.lddx + c4;
-      const long row_stride = (long)a.W * a.lddx;
-      f32x4_t acc[3];
-      uint2 oldv[3], mv[3];
+      f32x4_t acc[4];      // output rows y % 4: row y is complete after haloed row y + 2, written out during haloed row y + 3, re-used by row y + 4
+      uint2 oldv[4], mv[4];
+      // 108 fragment steps = 18 haloed rows x 3 column shifts x 2 K-chunks, up to 3 MFMAs each (the output rows yy, yy-1, yy-2).  Fragments are
+      // requested AHEAD steps before use; sched_barriers keep that order (left alone hipcc waits for each read right before its MFMAs).
+      constexpr int RING = 6, AHEAD = RING - 1, NF = PW * 6;
+      uint4 ring[RING];
+      auto frag = [&](int f) {
+        const int yy = f / 6, j = f - 6 * yy, C = yy * PW + (j >> 1);
+        return bw_lds16((d0[C & 7] ^ ((j & 1) << 6)) + C * DD_LDS_ROW);
+      };
+      auto write_row = [&](int y) {      // mask, round, (accumulate,) store output row y
+        const f32x4_t v = acc[y % 4];
+        uint2 o2;
+        o2.x = pack2<T>(v[0], v[1]);
+        o2.y = pack2<T>(v[2], v[3]);
+        if (MASK) { o2.x = mask_bf16x2(o2.x, mv[y % 4].x); o2.y = mask_bf16x2(o2.y, mv[y % 4].y); }
+        if (ACCUM) {
+          float f8[8], g8[8];
+          unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
+          unpack8t<T>(uint4{oldv[y % 4].x, oldv[y % 4].y, 0u, 0u}, g8);
+          o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
+          o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+        }
+        if (col_ok && oc.y0 + y < a.H) *reinterpret_cast<uint2*>(dxp + y * row_stride) = o2;
+      };
+#pragma unroll
+      for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
 #pragma unroll
       for (int yy = 0; yy < PW; ++yy) {
-        if (yy < DD_TILE) {
-          acc[yy % 3] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          mv[yy % 3] = bw_lds8(mrow + yy * DD_TILE * DD_LDS_ROW);
-          oldv[yy % 3] = uint2{0u, 0u};
-          if (a.accumulate && col_ok && oc.y0 + yy < a.H) oldv[yy % 3] = *reinterpret_cast<const uint2*>(dxp + yy * row_stride);
-        }
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-          if ((k * PW) / NP == yy) piece(k, on, sel ^ 1);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-          for (int kc = 0; kc < 2; ++kc) {
-            const int C = yy * PW + dx;      // (layers with <= 32 output channels multiply zeros for kc = 1: rare and small)
-            const uint4 f = bw_lds16((d0[C & 7] ^ (kc << 6)) + C * DD_LDS_ROW);
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-              const int y = yy - dy;
-              if (y >= 0 && y < DD_TILE) acc[y % 3] = mma16<T>(wf[dy * 3 + dx][kc], f, acc[y % 3]);
-            }
+        for (int j = 0; j < 6; ++j) {
+          const int f = yy * 6 + j, dx = j >> 1, kc = j & 1;      // (layers with <= 32 output channels multiply zeros for kc = 1: rare and small)
+          if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
+          if (j == 0 && yy < DD_TILE) {
+            acc[yy % 4] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (MASK) mv[yy % 4] = bw_lds8(mrow + yy * DD_TILE * DD_LDS_ROW);
+            oldv[yy % 4] = uint2{0u, 0u};
+            if (ACCUM && col_ok && oc.y0 + yy < a.H) oldv[yy % 4] = *reinterpret_cast<const uint2*>(dxp + yy * row_stride);
           }
-        if (yy >= 2) {      // output row y = yy - 2 is complete
-          const int y = yy - 2;
-          const f32x4_t v = acc[y % 3];
-          uint2 o2;
-          o2.x = pack2<T>(v[0], v[1]);
-          o2.y = pack2<T>(v[2], v[3]);
-          if (a.use_mask) { o2.x = mask_bf16x2(o2.x, mv[y % 3].x); o2.y = mask_bf16x2(o2.y, mv[y % 3].y); }
-          if (a.accumulate) {
-            float f8[8], g8[8];
-            unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
-            unpack8t<T>(uint4{oldv[y % 3].x, oldv[y % 3].y, 0u, 0u}, g8);
-            o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
-            o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+          if (j == 2 && yy >= 3) write_row(yy - 3);      // (under this row's MFMAs)
+          {      // the NP DMA pieces of the next tile, spread evenly over the NF steps (piece k at step k*NF/NP)
+            const int k0 = (f * NP + NF - 1) / NF;
+            if (k0 < NP && (k0 * NF) / NP == f) piece(k0, on, sel ^ 1);
           }
-          if (col_ok && oc.y0 + y < a.H) *reinterpret_cast<uint2*>(dxp + y * row_stride) = o2;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int y = yy - dy;
+            if (y >= 0 && y < DD_TILE) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], ring[f % RING], acc[y % 4]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      write_row(DD_TILE - 1);
+      const int flip = sel ? -BW_BUF : BW_BUF;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d0[c] += flip;
+      mrow += flip;
+      oc = on;
     }
   } else {
     // ================================================================== weight-gradient role: wave = output-channel tile wr
@@ -272,20 +292,14 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 
     int sel = 0;
     for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
-      launder();
-      const Origin on = origin(tile + a.ksplit);
-      if (!active) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) piece(k, on, sel ^ 1);
-        continue;
-      }
-      // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each; the dy fragment of step n+1 and (during taps 4..7) the x fragments of the next
-      // row pair are requested before the MFMAs of step n.  sched_barriers keep hipcc from hoisting a whole row pair's 26 reads (52 registers).
-      uint4 xf[2][4], df[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xf[0][i] = x_frag(0, i);
+      __syncthreads();      // the data-gradient waves' DMA of `tile` has landed (they wait for it before this barrier); buffer sel^1 is free
+      if (!active) continue;
+      // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each.  The dy fragment of step n+1 is requested before the MFMAs of step n; of the next
+      // row pair's four x fragments two are requested two taps early into a second buffer and two are re-read in place right after the last tap's
+      // MFMAs have issued (a full second set costs 8 more registers than this role has: 144 of its 256 are accumulators).  sched_barriers keep
+      // hipcc from hoisting a whole row pair's 26 reads (52 registers).
+      uint4 xa[2][2], xb[2], df[2];
+      xa[0][0] = x_frag(0, 0); xa[0][1] = x_frag(0, 1); xb[0] = x_frag(0, 2); xb[1] = x_frag(0, 3);
       df[0] = dy_frag(0);
 #pragma unroll
       for (int s = 0; s < 8; ++s)
@@ -293,19 +307,19 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       for (int t = 0; t < 9; ++t) {
         const int step = s * 9 + t;
         if (step + 1 < 72) df[(step + 1) & 1] = dy_frag(step + 1);
-        if (s + 1 < 8 && t >= 4 && t < 8) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
-#pragma unroll
-        for (int k = 0; k < NP; ++k)
-          if ((k * 72) / NP == step) piece(k, on, sel ^ 1);
+        if (s + 1 < 8 && (t == 6 || t == 7)) xa[(s + 1) & 1][t - 6] = x_frag(s + 1, t - 6);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = mma16<T>(xf[s & 1][i], df[step & 1], acc[t][i]);
+        bw_mma_inplace<T>(acc[t][0], xa[s & 1][0], df[step & 1]);
+        bw_mma_inplace<T>(acc[t][1], xa[s & 1][1], df[step & 1]);
+        bw_mma_inplace<T>(acc[t][2], xb[0], df[step & 1]);
+        bw_mma_inplace<T>(acc[t][3], xb[1], df[step & 1]);
         if (t == 4 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel wr*16 + li per lane
           float f[8];
           unpack8t<T>(df[step & 1], f);
           bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (t == 8 && s + 1 < 8) { xb[0] = x_frag(s + 1, 2); xb[1] = x_frag(s + 1, 3); }
       }
       // the other buffer next time
       const int flip = sel ? -BW_BUF : BW_BUF;
@@ -314,6 +328,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       qb[0] += flip; qb[1] += flip;
     }
 
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (see bw_mma_inplace)
     // flush: D[t][i] rows = input channels i*16 + q4 + e, column = output channel wr*16 + li; shifted-dy tap t is TensorFlow's tap 8 - t
     if (active) {
       const int co = wr * 16 + li;
@@ -350,18 +365,23 @@ static int bwd_cus() {
   return n;
 }
 
-template <typename T>
-int launch_bwd(BwdP& p, hipStream_t stream) {
+template <typename T, bool MASK, bool ACCUM>
+int launch_bwd_flags(const BwdP& p, hipStream_t stream) {
   const size_t lds = 2 * (size_t)BW_BUF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<T, MASK, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long blocks = (long)p.nblk * p.ksplit;
-  hipLaunchKernelGGL((conv_bwd_kernel<T>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((conv_bwd_kernel<T, MASK, ACCUM>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
+}
+template <typename T>
+int launch_bwd(const BwdP& p, hipStream_t stream) {
+  if (p.use_mask) return p.accumulate ? launch_bwd_flags<T, true, true>(p, stream) : launch_bwd_flags<T, true, false>(p, stream);
+  return p.accumulate ? launch_bwd_flags<T, false, true>(p, stream) : launch_bwd_flags<T, false, false>(p, stream);
 }
 
 }  // namespace
