@@ -94,6 +94,16 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int per_img = a.tiles_y * a.tiles_x;
   const int total_tiles = a.B * per_img;
+  // Tile sequence of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2: iteration i of
+  // the ksplit workgroups of a block covers ksplit consecutive tiles, and the ksplit/8 workgroups of ONE XCD take a contiguous run of them, so
+  // that neighbouring tiles -- which share their dy halo rows and columns -- meet in the same L2.
+#ifdef CBW_EXP_NO_XCD
+  const int xcd_n = 1;
+#else
+  const int xcd_n = (a.ksplit & 7) == 0 ? 8 : 1;
+#endif
+  const int per_xcd = a.ksplit / xcd_n;
+  const int tile0 = (ks % xcd_n) * per_xcd + ks / xcd_n;      // first tile; then + ksplit per iteration
 
   if (wave < 4) {
     // ================================================================== data-gradient role: wave = input-channel tile wr of this block
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
         }
       }
     };
-    Origin oc = origin(ks);
+    Origin oc = origin(tile0);
 #pragma unroll
     for (int k = 0; k < NP; ++k) piece(k, oc, 0);
 
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
     const long row_stride = (long)a.W * a.lddx;
 
     int sel = 0;
-    for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+    for (int tile = tile0; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
       __syncthreads();                      // ... and everyone's; buffer sel^1 is free
       const Origin on = origin(tile + a.ksplit);
@@ -291,15 +301,14 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
     };
 
     int sel = 0;
-    for (int tile = ks; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+    for (int tile = tile0; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
       __syncthreads();      // the data-gradient waves' DMA of `tile` has landed (they wait for it before this barrier); buffer sel^1 is free
       if (!active) continue;
-      // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each.  The dy fragment of step n+1 is requested before the MFMAs of step n; of the next
-      // row pair's four x fragments two are requested two taps early into a second buffer and two are re-read in place right after the last tap's
-      // MFMAs have issued (a full second set costs 8 more registers than this role has: 144 of its 256 are accumulators).  sched_barriers keep
-      // hipcc from hoisting a whole row pair's 26 reads (52 registers).
-      uint4 xa[2][2], xb[2], df[2];
-      xa[0][0] = x_frag(0, 0); xa[0][1] = x_frag(0, 1); xb[0] = x_frag(0, 2); xb[1] = x_frag(0, 3);
+      // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each; the dy fragment of step n+1 and (during taps 4..7) the x fragments of the next
+      // row pair are requested before the MFMAs of step n.  sched_barriers keep hipcc from hoisting a whole row pair's 26 reads (52 registers).
+      uint4 xf[2][4], df[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[0][i] = x_frag(0, i);
       df[0] = dy_frag(0);
 #pragma unroll
       for (int s = 0; s < 8; ++s)
@@ -307,19 +316,16 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       for (int t = 0; t < 9; ++t) {
         const int step = s * 9 + t;
         if (step + 1 < 72) df[(step + 1) & 1] = dy_frag(step + 1);
-        if (s + 1 < 8 && (t == 6 || t == 7)) xa[(s + 1) & 1][t - 6] = x_frag(s + 1, t - 6);
+        if (s + 1 < 8 && t >= 4 && t < 8) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
         __builtin_amdgcn_sched_barrier(0);
-        bw_mma_inplace<T>(acc[t][0], xa[s & 1][0], df[step & 1]);
-        bw_mma_inplace<T>(acc[t][1], xa[s & 1][1], df[step & 1]);
-        bw_mma_inplace<T>(acc[t][2], xb[0], df[step & 1]);
-        bw_mma_inplace<T>(acc[t][3], xb[1], df[step & 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], df[step & 1]);
         if (t == 4 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel wr*16 + li per lane
           float f[8];
           unpack8t<T>(df[step & 1], f);
           bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t == 8 && s + 1 < 8) { xb[0] = x_frag(s + 1, 2); xb[1] = x_frag(s + 1, 3); }
       }
       // the other buffer next time
       const int flip = sel ? -BW_BUF : BW_BUF;
