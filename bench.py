@@ -318,6 +318,13 @@ def main():
                              "frac": alg_bytes / n / (1e-3 * ms / n) / 1e9 / PEAK_HBM_GBS,
                              "flop_per_byte": flops / alg_bytes, "ridge_flop_per_byte": 1e3 * peak / PEAK_HBM_GBS},
                 "other_kernels_ms_per_step": {k: round(v[1], 3) for k, v in times.items() if k != fam}}
+        # every MFMA conv family of the step (conv_bwd = the fused data + weight gradient launch of csrc/dd_conv_bwd.hip, conv_wgrad = the
+        # weight-gradient launches of the layers it does not cover) and their aggregate: the step's conv FLOPs over the time of all of them
+        convs = {k: times[k] for k in ("conv_igemm", "conv_bwd", "conv_wgrad") if k in times and times[k][1] > 0}
+        roof["mfma_families"] = {k: {"launches_per_step": v[0], "ms_per_step": round(v[1], 3), "tflops": v[2] / (v[1] * 1e-3) / 1e12,
+                                     "frac": v[2] / (v[1] * 1e-3) / 1e12 / peak} for k, v in convs.items()}
+        tot_ms, tot_fl = sum(v[1] for v in convs.values()), sum(v[2] for v in convs.values())
+        roof["all_conv_launches"] = {"ms_per_step": round(tot_ms, 3), "tflops": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak}
     if rank == 0:
         out = {
             "metric": "train tiles/sec (128x128x32ch U-Net KPCN)", "value": world * B * args.steps / dt, "unit": "tiles/s",
