@@ -212,7 +212,7 @@ class Graph:
         self.layers = {}
         self.keep = []     # keeps auxiliary device buffers alive
         self.zero_init_buffers = []     # gradient buffers with several partial-range writers: zeroed before every backward pass
-        self.conv_records, self.wgrad_records, self.bwd_records = [], [], []
+        self.conv_records, self.wgrad_records, self.bwd_records, self.convt_records = [], [], [], []
         self._pack_records = []
 
     # ------------------------------------------------------------------ weight packing: every layer in ONE launch
@@ -330,6 +330,31 @@ class Graph:
         run.info = self.bwd_records[-1]
         return run
 
+    def _convt_call(self, x, y, layer, w, n_pad, k_pad, relu, gx=None, use_mask=False, accumulate=False):
+        """2x2 / stride-2 transposed conv: forward (gx is None; y = output) or the fused backward (y = dy) -- csrc/dd_convt.hip."""
+        B, H, W = x.B, x.H, x.W
+        bwd = gx is not None
+        self.convt_records.append({"flops": (3 if bwd else 1) * 2.0 * B * H * W * 4 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 4,
+                                   "n": layer.cout, "k": layer.cin, "backward": bwd})
+        ps = self.params
+        a = L.ConvTArgs()
+        a.x, a.ld_x, a.cin = x.ptr, x.ld, layer.cin
+        a.y, a.ld_y, a.cout = y.ptr, y.ld, layer.cout
+        a.w, a.n_pad, a.k_pad = w.data_ptr(), n_pad, k_pad
+        a.bias, a.relu = (None if bwd else ps.value_ptr(layer.bias)), int(bool(relu))
+        if bwd:
+            a.dx, a.ld_dx, a.dw, a.db = gx.ptr, gx.ld, ps.grad_ptr(layer.kernel), ps.grad_ptr(layer.bias)
+        a.use_mask, a.accumulate = int(bool(use_mask)), int(bool(accumulate))
+        a.B, a.H, a.W, a.dtype = B, H, W, self.code
+        lib = self.lib
+        keep = (x.buf, y.buf, w, gx.buf if bwd else None)
+        fn = lib.dd_convt2x2_bwd if bwd else lib.dd_convt2x2_fwd
+
+        def run(stream, a=a, keep=keep):
+            L.check(fn(C.byref(a), stream))
+        run.info = self.convt_records[-1]
+        return run
+
     def _bias_grad_call(self, gy, cout, bias_param):
         lib, code, ps = self.lib, self.code, self.params
 
@@ -430,15 +455,28 @@ class Graph:
         y.relu = relu
         ps = self.params
         wp, taps, n_pad, k_pad = layer.packed("fwd")
-        flags = L.PIXSHUF | (L.OUT_RELU if relu else 0)
-        yv = DT(y.buf, y.B, y.H, y.W, 4 * layer.cout, 4 * layer.cout, y.ch0, y.dtype)   # n = (a,b,co)
-        self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, yv,
-                                                     x.B, x.H, x.W, flags, nk=(4 * layer.cout, layer.cin)), "conv_igemm"))
+        # streaming kernels of csrc/dd_convt.hip (bf16 / f16 storage): forward for <= 96 output channels, fused backward for <= 64
+        stream_ok = (self.dtype in ("bf16", "f16") and layer.cin <= 128 and layer.cout % 16 == 0 and os.environ.get("DD_CONVT_STREAM", "1") != "0")
+        if stream_ok and layer.cout <= 96:
+            self.fwd(self._defer(lambda: self._convt_call(x, y, layer, wp, n_pad, k_pad, relu), "convt"))
+        else:
+            flags = L.PIXSHUF | (L.OUT_RELU if relu else 0)
+            yv = DT(y.buf, y.B, y.H, y.W, 4 * layer.cout, 4 * layer.cout, y.ch0, y.dtype)   # n = (a,b,co)
+            self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, yv,
+                                                         x.B, x.H, x.W, flags, nk=(4 * layer.cout, layer.cin)), "conv_igemm"))
 
         def backward():
             if not y.grad_written:
                 return
             gy = y.grad()
+            if stream_ok and layer.cout <= 64 and x.requires_grad:
+                wd, _, dn_pad, dk_pad = layer.packed("dgrad")
+                gx = x.grad()
+                use_mask, accumulate = x.relu, x.grad_written
+                self.bwd(self._defer(lambda: self._convt_call(x, gy, layer, wd, dn_pad, dk_pad, False, gx=gx, use_mask=use_mask, accumulate=accumulate),
+                                     "convt"), grad_params=[layer.kernel, layer.bias])
+                x.mark_grad_written()
+                return
             self.bwd(self._defer(lambda: self._wgrad_call(gy, layer.cout, x, layer.cin, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, 4, L.GATHER2X2,
                                                           ps.grad_ptr(layer.bias), 2), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])
             if x.requires_grad:

@@ -110,6 +110,26 @@ typedef struct {
 } dd_conv_bwd_args;
 int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream);
 
+/* ---- 2x2 / stride-2 transposed convolution (tf.layers.conv2d_transpose(filters, 2, strides=2), UNet.py:54-59) as streaming kernels: the
+ * forward (+ bias, ReLU), and the data + weight + bias gradients of TensorFlow's autodiff (Training.py:701-702) in ONE launch.  bf16 / f16
+ * storage, cin <= 128, cout a multiple of 16 (<= 96 forward, <= 64 backward).  x [B,H,W,ld_x], y / dy [B,2H,2W,ld_y];
+ * kernel K[a][b][co][ci] (TensorFlow layout [2][2][cout][cin]):
+ *   forward : y[2i+a][2j+b][co] = act(bias[co] + sum_ci x[i][j][ci] K[a][b][co][ci]);  w = dd_pack_weights layout [4*cout -> n_pad][k_pad (ci)]
+ *   backward: dx[i][j][ci] = (use_mask ? x > 0 : 1) * sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci]   (accumulate: added to dx);
+ *             dw[a][b][co][ci] += sum_{i,j} dy[2i+a][2j+b][co] x[i][j][ci];  db[co] += sum dy (db may be NULL); fp32 atomics: zero them first;
+ *             w = the data-gradient pack [4][n_pad (ci)][k_pad (co)] */
+typedef struct {
+  const void* x; int ld_x; int cin;
+  void* y; int ld_y; int cout;         /* forward: output; backward: dy (read only) */
+  const void* w; int n_pad; int k_pad;
+  const float* bias; int relu;         /* forward only */
+  void* dx; int ld_dx; float* dw; float* db; int use_mask; int accumulate;      /* backward only */
+  int B, H, W;                         /* INPUT grid */
+  int dtype;
+} dd_convt_args;
+int dd_convt2x2_fwd(const dd_convt_args* a, dd_stream stream);
+int dd_convt2x2_bwd(const dd_convt_args* a, dd_stream stream);
+
 /* column sums: out[c] += sum_rows x[row*ld + c]  (bias gradients; embedding-row gradients) */
 int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream);
 

@@ -205,7 +205,7 @@ def test_conv_grad_accumulation_and_concat_views(eng, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("cin,cout,H,W", [(128, 96, 8, 8), (96, 64, 16, 16), (32, 16, 12, 20)])
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 96, 8, 8), (96, 64, 16, 16), (32, 16, 12, 20), (96, 64, 13, 9), (128, 64, 24, 16), (72, 48, 5, 30)])
 def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
     B = 2
     gen = _gen(cin + cout)
