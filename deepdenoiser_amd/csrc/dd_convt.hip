@@ -34,7 +34,7 @@ typedef uint32_t ct_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int CT_T = 8;                                             // input pixels per tile side
 constexpr int CT_X_SLICE = CT_T * CT_T * DD_LDS_ROW;                // x image of one 64-channel slice: 64 pixels x 128 bytes
 constexpr int CT_X_BYTES = 2 * CT_X_SLICE;                          // C_in <= 128
-constexpr int CT_Y_BYTES = 4 * CT_T * CT_T * DD_LDS_ROW;            // dy image: 16 x 16 pixels x 128 bytes (C_out <= 64)
+constexpr int CT_Y_BYTES = 4 * CT_T * CT_T * DD_LDS_ROW;            // dy image: 32 KiB = 16 x 16 pixels x 64 channels, or (C_out > 64) two 64-channel slices of 16 x 8
 constexpr int CT_BWD_BUF = CT_Y_BYTES + CT_X_BYTES;                 // 48 KiB
 constexpr int CT_FWD_BUF = CT_X_BYTES;                              // 16 KiB
 
@@ -57,28 +57,32 @@ __device__ __forceinline__ uint4 ct_tr_pair(unsigned a0, unsigned a1) {
 }
 
 struct CtTile { int b, i0, j0; bool live; };
-__device__ __forceinline__ CtTile ct_tile(const CtP& a, int tile, int total) {
+__device__ __forceinline__ CtTile ct_tile(const CtP& a, int tile, int total, int th = CT_T) {      // tiles are 8 input pixels wide, th high
   CtTile t;
   t.live = tile < total;
   const int u = t.live ? tile : 0, per_img = a.tiles_x * a.tiles_y;
   t.b = u / per_img;
   const int rem = u - t.b * per_img, ty = rem / a.tiles_x;
-  t.i0 = ty * CT_T; t.j0 = (rem - ty * a.tiles_x) * CT_T;
+  t.i0 = ty * th; t.j0 = (rem - ty * a.tiles_x) * CT_T;
   return t;
 }
 // DMA of the x tile (8x8 input pixels, two 64-channel slices): 16 chunks, chunk xc = slice * 8 + tile row; a lane fetches pixel r = lane >> 3 of
 // the row, logical 16-byte slot ls = (lane & 7) ^ r
+template <int TH = CT_T>
 __device__ __forceinline__ void ct_dma_x(const CtP& a, const CtTile& t, int xc, unsigned lds, int lane) {
   const int r = lane >> 3, ls = (lane & 7) ^ r;
-  const int sx = xc >> 3, row = xc & 7, ch = sx * 64 + ls * 8;
+  const int sx = xc / TH, row = xc % TH, ch = sx * 64 + ls * 8;
   const bool ok = t.live && ch < a.cinv && t.i0 + row < a.H && t.j0 + r < a.W;
   const char* src = reinterpret_cast<const char*>(a.x) + (((long)t.b * a.H + t.i0 + row) * a.W + t.j0 + r) * a.ldx * 2 + ch * 2;
   ct_dma_1k(ok ? src : reinterpret_cast<const char*>(&dd_zero16_v), lds + xc * 1024);
 }
-// DMA of the dy tile (16x16 output pixels, <= 64 channels): 32 chunks, chunk c = output row c >> 1, pixels (c & 1) * 8 + r
+// DMA of the dy tile (NSD 64-channel slices of 16 x 16/NSD output pixels): 32 chunks, chunk c = slice c / (32/NSD), output row (c % (32/NSD)) >> 1,
+// pixels (c & 1) * 8 + r
+template <int NSD>
 __device__ __forceinline__ void ct_dma_y(const CtP& a, const CtTile& t, int c, unsigned lds, int lane) {
   const int r = lane >> 3, ls = (lane & 7) ^ r;
-  const int row = c >> 1, col = (c & 1) * 8 + r, ch = ls * 8;
+  const int sd = c / (32 / NSD), cc = c % (32 / NSD);
+  const int row = cc >> 1, col = (cc & 1) * 8 + r, ch = sd * 64 + ls * 8;
   const int gy = 2 * t.i0 + row, gx = 2 * t.j0 + col;
   const bool ok = t.live && ch < a.coutv && gy < 2 * a.H && gx < 2 * a.W;
   const char* src = reinterpret_cast<const char*>(a.y) + (((long)t.b * 2 * a.H + gy) * 2 * a.W + gx) * a.ldy * 2 + ch * 2;
@@ -172,17 +176,32 @@ __global__ __launch_bounds__(512) void convt_fwd_kernel(const CtP a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ backward
-template <typename T, bool MASK, bool ACCUM>
+// acc += A * B with the accumulator tied to one register tuple (see csrc/dd_conv_bwd.hip: through the builtin hipcc renames long-lived accumulator
+// tuples and spills; these are touched once per K step and read only after the tile loop, behind explicit s_nops)
+template <typename T> __device__ __forceinline__ void ct_mma_inplace(f32x4_t& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void ct_mma_inplace<bf16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
+  const ct_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+}
+template <> __device__ __forceinline__ void ct_mma_inplace<f16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
+  const ct_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+}
+
+// NSD = 64-channel slices of dy (1: C_out <= 64, tiles of 8 x 8 input pixels; 2: C_out <= 128, tiles of 8 x 4 -- the dy image stays 32 KiB)
+template <typename T, int NSD, bool MASK, bool ACCUM>
 __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int TH = CT_T / NSD, NG = TH / 2, KC = 2 * NSD, JW = 2 * NSD, KS = TH / 4;      // tile rows, 16-pixel groups, K chunks of dx, output-channel tiles per wave of dK, K steps of dK
+  constexpr int Y_SLICE = CT_Y_BYTES / NSD, X_SLICE = CT_T * TH * DD_LDS_ROW, BUF = CT_Y_BYTES + 2 * X_SLICE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, q = lane >> 4;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int total = a.B * a.tiles_x * a.tiles_y;
 
-  // ---- data gradient: wave = input-channel tile `wave` (16 channels), all 64 input pixels of the tile in 4 groups of 16 (2 tile rows)
+  // ---- data gradient: wave = input-channel tile `wave` (16 channels), all input pixels of the tile in NG groups of 16 (2 tile rows)
   const bool d_active = wave * 16 < a.cin;
-  uint4 wf[4][2];                  // [tap][K chunk of 32 output channels]
+  uint4 wf[4][KC];                 // [tap][K chunk of 32 output channels]
   {
     const T* Wd = reinterpret_cast<const T*>(a.w);
     const T* zw = reinterpret_cast<const T*>(&dd_zero16_v);
@@ -190,14 +209,14 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
+      for (int kc = 0; kc < KC; ++kc) {
         const int k0 = kc * 32 + q * 8;
         const bool ok = ci_row < a.n_pad && k0 < a.k_pad;
         wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + k0 : zw);
       }
   }
   // dy image addresses: input pixel (2g + (li >> 3), li & 7) of group g, tap (ta, tb) -> dy pixel pd = (2*row + ta) * 16 + 2*col + tb;
-  // group g adds 64 pixels; K chunk kc = slot kc*4 + q; swizzle key pd & 7 = (2*col + tb) & 7
+  // group g adds 64 pixels; K chunk kc = slice kc >> 1, slot (kc & 1)*4 + q; swizzle key pd & 7 = (2*col + tb) & 7
   unsigned db[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -205,13 +224,13 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     db[t] = lds_base + pd * DD_LDS_ROW + ((q ^ (pd & 7)) << 4);
   }
   // x image (behind the dy image): mask of this lane's results = pixel g*16 + li, channels wave*16 + q*4 ..
-  const unsigned mb = lds_base + CT_Y_BYTES + (wave >> 2) * CT_X_SLICE + li * DD_LDS_ROW + ((((wave & 3) * 2 + (q >> 1)) ^ (li & 7)) << 4) + (q & 1) * 8;
+  const unsigned mb = lds_base + CT_Y_BYTES + (wave >> 2) * X_SLICE + li * DD_LDS_ROW + ((((wave & 3) * 2 + (q >> 1)) ^ (li & 7)) << 4) + (q & 1) * 8;
   const int c4 = wave * 16 + q * 4;
   T* __restrict__ DX = reinterpret_cast<T*>(a.out);
 
-  // ---- weight gradient: wave = tap tw x half h of the output channels (output-channel tiles 2h, 2h+1) x all 8 input-channel tiles
+  // ---- weight gradient: wave = tap tw x half h of the output channels (output-channel tiles h*JW .. h*JW + JW-1) x all 8 input-channel tiles
   const int tw = wave & 3, h = wave >> 2;
-  const bool w_active = h * 32 < a.cout;
+  const bool w_active = h * JW * 16 < a.cout;
   const int nci = (a.cin + 15) >> 4;
   unsigned yb[2], xb[2];           // transposed reads: lane (t16, gq): pixel row gq (of the 4 rows of a K step), column (t16 >> 2) [+ 4], 4-channel piece t16 & 3
   {
@@ -220,40 +239,43 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     for (int hh = 0; hh < 2; ++hh) {
       const int col = (t16 >> 2) + 4 * hh;
       const int pd = (2 * gq + (tw >> 1)) * 16 + 2 * col + (tw & 1), px = gq * 8 + col;
-      yb[hh] = lds_base + pd * DD_LDS_ROW + (((h * 4 + (sub >> 1)) ^ (pd & 7)) << 4) + (sub & 1) * 8;          // output-channel tile 2h; tile 2h+1: ^ 32
+      // output-channel tile h*JW + j: slice (h*JW + j) >> 2 (NSD = 2: slice h), slot ((h*JW + j) & 3)*2 + (sub >> 1): j enters as ^ (j << 5)
+      yb[hh] = lds_base + ((h * JW) >> 2) * Y_SLICE + pd * DD_LDS_ROW + (((((h * JW) & 3) * 2 + (sub >> 1)) ^ (pd & 7)) << 4) + (sub & 1) * 8;
       xb[hh] = lds_base + CT_Y_BYTES + px * DD_LDS_ROW + (((sub >> 1) ^ (px & 7)) << 4) + (sub & 1) * 8;        // input-channel tile 0; tile i: ^ ((i & 3) << 5), + (i >> 2) * slice
     }
   }
-  f32x4_t wacc[2][8];
+  f32x4_t wacc[JW][8];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < JW; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) wacc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
+  float bsum[JW];
+#pragma unroll
+  for (int j = 0; j < JW; ++j) bsum[j] = 0.f;
 
-  // ---- DMA: 48 chunks per tile (32 dy + 16 x), 6 per wave, all issued right behind the barrier: the arithmetic of a tile is short
+  // ---- DMA: 32 dy + 2*TH x chunks per tile, 5-6 per wave, all issued right behind the barrier: the arithmetic of a tile is short
   auto dma_tile = [&](const CtTile& t, unsigned buf) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ct_dma_y(a, t, k * 8 + wave, buf, lane);
-    ct_dma_x(a, t, wave, buf + CT_Y_BYTES, lane);
-    ct_dma_x(a, t, wave + 8, buf + CT_Y_BYTES, lane);
+    for (int k = 0; k < 4; ++k) ct_dma_y<NSD>(a, t, k * 8 + wave, buf, lane);
+    ct_dma_x<TH>(a, t, wave, buf + CT_Y_BYTES, lane);
+    if (NSD == 1) ct_dma_x<TH>(a, t, wave + 8, buf + CT_Y_BYTES, lane);
   };
-  CtTile cur = ct_tile(a, blockIdx.x, total);
+  CtTile cur = ct_tile(a, blockIdx.x, total, TH);
   dma_tile(cur, lds_base);
   int sel = 0;
   for (int tile = blockIdx.x; tile < total; tile += a.nwg, sel ^= 1) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    const CtTile nxt = ct_tile(a, tile + a.nwg, total);
-    dma_tile(nxt, lds_base + (sel ^ 1) * CT_BWD_BUF);
-    const unsigned bt = sel * CT_BWD_BUF;
+    const CtTile nxt = ct_tile(a, tile + a.nwg, total, TH);
+    dma_tile(nxt, lds_base + (sel ^ 1) * BUF);
+    const unsigned bt = sel * BUF;
     if (d_active) {
-      f32x4_t acc[4];
-      uint2 mv[4], oldv[4];
+      f32x4_t acc[NG];
+      uint2 mv[NG], oldv[NG];
       const int jj = cur.j0 + (li & 7);
       const bool ch_ok = c4 < a.cinv && jj < a.W;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < NG; ++g) {
         acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (MASK) mv[g] = ct_lds8(bt + mb + g * 16 * DD_LDS_ROW);
         oldv[g] = uint2{0u, 0u};
@@ -263,14 +285,14 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const uint4 f = ct_lds16(bt + (db[t] ^ (kc << 6)) + g * 64 * DD_LDS_ROW);
+          for (int g = 0; g < NG; ++g) {
+            const uint4 f = ct_lds16(bt + (db[t] ^ ((kc & 1) << 6)) + (kc >> 1) * Y_SLICE + g * 64 * DD_LDS_ROW);
             acc[g] = mma16<T>(wf[t][kc], f, acc[g]);
           }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < NG; ++g) {
         const int ii = cur.i0 + 2 * g + (li >> 3);
         uint2 o2;
         o2.x = pack2<T>(acc[g][0], acc[g][1]);
@@ -288,22 +310,22 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     }
     if (w_active) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {      // K step = 32 input pixels = tile rows 4s .. 4s+3  (dy rows 8s .. 8s+7: + 128 pixels)
-        uint4 yf[2];
+      for (int s = 0; s < KS; ++s) {      // K step = 32 input pixels = tile rows 4s .. 4s+3  (dy rows 8s .. 8s+7: + 128 pixels)
+        uint4 yf[JW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JW; ++j)
           yf[j] = ct_tr_pair(bt + (yb[0] ^ (j << 5)) + s * 128 * DD_LDS_ROW, bt + (yb[1] ^ (j << 5)) + s * 128 * DD_LDS_ROW);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           if (i >= nci) continue;
-          const uint4 xf = ct_tr_pair(bt + (xb[0] ^ ((i & 3) << 5)) + (i >> 2) * CT_X_SLICE + s * 32 * DD_LDS_ROW,
-                                      bt + (xb[1] ^ ((i & 3) << 5)) + (i >> 2) * CT_X_SLICE + s * 32 * DD_LDS_ROW);
+          const uint4 xf = ct_tr_pair(bt + (xb[0] ^ ((i & 3) << 5)) + (i >> 2) * X_SLICE + s * 32 * DD_LDS_ROW,
+                                      bt + (xb[1] ^ ((i & 3) << 5)) + (i >> 2) * X_SLICE + s * 32 * DD_LDS_ROW);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) wacc[j][i] = mma16<T>(yf[j], xf, wacc[j][i]);      // D[co][ci]
+          for (int j = 0; j < JW; ++j) ct_mma_inplace<T>(wacc[j][i], yf[j], xf);      // D[co][ci]
         }
         if (a.db) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {      // A fragment: 8 pixels of output channel (2h + j)*16 + li per lane
+          for (int j = 0; j < JW; ++j) {      // A fragment: 8 pixels of output channel (h*JW + j)*16 + li per lane
             float f[8];
             unpack8t<T>(yf[j], f);
             bsum[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
@@ -313,27 +335,28 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     }
     cur = nxt;
   }
-  // flush: D[j][i] rows = output channels (2h + j)*16 + q*4 + e, column = input channel i*16 + li; TensorFlow layout [a][b][co][ci]
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (see ct_mma_inplace)
+  // flush: D[j][i] rows = output channels (h*JW + j)*16 + q*4 + e, column = input channel i*16 + li; TensorFlow layout [a][b][co][ci]
   if (w_active) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JW; ++j)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int ci = i * 16 + li;
         if (i >= nci || ci >= a.cin) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int co = (2 * h + j) * 16 + q * 4 + e;
+          const int co = (h * JW + j) * 16 + q * 4 + e;
           if (co < a.cout) atomicAdd(a.dw + ((long)tw * a.cout + co) * a.cin + ci, wacc[j][i][e]);
         }
       }
     if (a.db) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < JW; ++j) {
         float b = bsum[j];
         b += __shfl_xor(b, 16);
         b += __shfl_xor(b, 32);
-        const int co = (2 * h + j) * 16 + li;
+        const int co = (h * JW + j) * 16 + li;
         if (lane < 16 && co < a.cout) atomicAdd(a.db + co, b);
       }
     }
@@ -357,6 +380,7 @@ static void ct_launch(K kernel, const CtP& p, size_t lds, hipStream_t stream) {
 }
 
 static int ct_fill(CtP& p, const dd_convt_args* a, bool bwd) {
+  const int th = (bwd && a && a->cout > 64) ? CT_T / 2 : CT_T;      // backward with two dy slices: tiles of 8 x 4
   DD_REQUIRE(a && a->x && a->y && a->w, "dd_convt2x2: null pointer");
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_convt2x2: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm / dd_conv_wgrad)", a->dtype);
   DD_REQUIRE(a->cin > 0 && a->cin <= 128 && a->cout > 0 && a->cout <= (bwd ? 64 : 96) && a->cout % 16 == 0,
@@ -368,7 +392,7 @@ static int ct_fill(CtP& p, const dd_convt_args* a, bool bwd) {
   p.x = a->x; p.y = a->y; p.w = a->w; p.ldx = a->ld_x; p.ldy = a->ld_y;
   p.cin = a->cin; p.cout = a->cout; p.cinv = cinv; p.coutv = coutv; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
   p.B = a->B; p.H = a->H; p.W = a->W;
-  p.tiles_x = dd_ceil_div(a->W, CT_T); p.tiles_y = dd_ceil_div(a->H, CT_T);
+  p.tiles_x = dd_ceil_div(a->W, CT_T); p.tiles_y = dd_ceil_div(a->H, th);
   const long total = (long)a->B * p.tiles_x * p.tiles_y;
   p.nwg = (int)(total < ct_cus() ? total : ct_cus());
   p.relu = a->relu;
@@ -407,12 +431,16 @@ extern "C" int dd_convt2x2_bwd(const dd_convt_args* a, dd_stream stream) {
   DD_REQUIRE(a->ld_dx % 4 == 0 && cinv <= a->ld_dx && ((uintptr_t)a->dx % 8) == 0, "dd_convt2x2_bwd: ld_dx=%d / dx alignment", a->ld_dx);
   p.out = a->dx; p.ldo = a->ld_dx; p.dw = a->dw; p.db = a->db; p.bias = nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t lds = 2 * (size_t)CT_BWD_BUF;
-#define CT_BWD(T)                                                                                          \
-  if (a->use_mask) { if (a->accumulate) ct_launch(convt_bwd_kernel<T, true, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, true, false>, p, lds, s); } \
-  else { if (a->accumulate) ct_launch(convt_bwd_kernel<T, false, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, false, false>, p, lds, s); }
+  const size_t lds = 2 * (size_t)CT_BWD_BUF;      // (two dy slices: 2 x 40 KiB are used)
+#define CT_BWD_N(T, N)                                                                                     \
+  if (a->use_mask) { if (a->accumulate) ct_launch(convt_bwd_kernel<T, N, true, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, N, true, false>, p, lds, s); } \
+  else { if (a->accumulate) ct_launch(convt_bwd_kernel<T, N, false, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, N, false, false>, p, lds, s); }
+  // (NSD = 2 -- two dy slices, C_out <= 128 -- compiles but spills 11 registers next to the in-place asm MFMAs, whose results the compiler may then
+  //  store before they are written: measured wrong in f16.  Only the spill-free NSD = 1 is instantiated; wider layers take the layer-wise path.)
+#define CT_BWD(T) CT_BWD_N(T, 1)
   if (a->dtype == DD_BF16) { CT_BWD(bf16_t) } else { CT_BWD(f16_t) }
 #undef CT_BWD
+#undef CT_BWD_N
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
