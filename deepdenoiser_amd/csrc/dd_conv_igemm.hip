@@ -932,6 +932,9 @@ int dispatch(ConvP& p, hipStream_t stream) {
 
 }  // namespace
 
+bool dd_conv_rw_eligible(const dd_conv_args* a);
+int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream);
+
 extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->x && a->wp && a->y, "dd_conv_igemm: null pointer");
   DD_REQUIRE(dd_dtype_ok(a->dtype), "dd_conv_igemm: bad dtype %d", a->dtype);
@@ -948,6 +951,8 @@ extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   DD_REQUIRE(a->ldy % 4 == 0 && (!a->res || a->ldres % 4 == 0) && (!a->mask || a->ldmask % 4 == 0), "dd_conv_igemm: ld must be multiple of 4");
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "dd_conv_igemm: empty grid");
   DD_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 16) == 0, "dd_conv_igemm: pointers must be 16-byte aligned");
+  // 3x3 layers with 65..96 input channels: weights in registers instead of LDS (csrc/dd_conv_rw.hip)
+  if (dd_conv_rw_eligible(a)) return dd_conv_rw_launch(a, reinterpret_cast<hipStream_t>(stream));
 
   ConvP p;
   p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.res = a->res; p.mask = a->mask; p.y = a->y;

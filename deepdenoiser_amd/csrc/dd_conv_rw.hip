@@ -1,0 +1,242 @@
+// 3x3 SAME convolution with REGISTER-resident weights on CDNA4: the launch dd_conv_igemm uses for layers whose reduction depth is 65..96
+// channels (the U-Net's 96-channel level: forward and data gradient, Training.py:701-702 over UNet.py:38-48).
+//
+// Why a second kernel.  csrc/dd_conv_igemm.hip keeps a layer's weights in LDS; 9 x 96 x 96 bf16 weights are 166 KB, 6 KB more than a CU has, so
+// those layers run as two 48-channel blocks -- every input tile is staged twice, each pass with two K slices of their own barriers -- and sit
+// at ~690 TFLOP/s where the 64-channel layers reach 900.  Here the weights of a wave's 16 output channels live in its registers as the MFMA A
+// operand (9 taps x 3 K-chunks = 27 fragments = 108 VGPRs), the pixels are the B operand, and LDS holds nothing but the input tile:
+//   * waves 0-5 = the six 16-channel tiles of a 96-channel output block; each walks the 10 haloed rows of a 16 x 8 pixel tile once: a row's
+//     fragment feeds the three output rows it touches (rotating accumulators), an output row is finished two haloed rows later and leaves
+//     straight from the accumulators (bias / ReLU / mask / accumulate fused), 4 channels = 8 bytes per lane;
+//   * waves 6-7 do nothing but LDS-DMA: the next tile (18 x 10 haloed pixels, two 64-channel slices, 46 chunks of 1 KiB) streams in while this
+//     one is multiplied.  The compute waves issue no DMA, so their vmcnt only ever waits for their own mask / gradient loads.
+// Output channels beyond 96 run as further blocks (the input is re-read per block).
+#include "dd_common.h"
+
+namespace {
+
+struct RwP {
+  const void* x; const void* wp; const float* bias; const void* mask; void* y;
+  int ldx, ldmask, ldy;
+  int cin, cinv, n, n_pad, k_pad, nbias;
+  int B, H, W, tiles_x, tiles_y, nblk, ksplit;
+  int relu, accum;
+};
+
+typedef uint32_t rw_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int RW_TW = 16, RW_TH = 8, RW_PW = RW_TW + 2, RW_PH = RW_TH + 2;      // tile and haloed tile
+constexpr int RW_CH = (RW_PW * RW_PH + 7) / 8;                                 // 23 chunks of 8 pixels per 64-channel slice
+constexpr int RW_SLICE = RW_CH * 1024, RW_BUF = 2 * RW_SLICE;                  // 46 KiB per buffer
+
+__device__ __forceinline__ void rw_dma_1k(const void* gptr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint4 rw_lds16(unsigned off) {
+  const rw_u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) rw_u32x4*>(off);
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+
+struct RwTile { int b, y0, x0; bool live; };
+
+template <typename T, int KC, bool MASK, bool ACCUM>
+__global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  static_assert(sizeof(T) == 2, "register-weight conv: bf16 / fp16 storage");
+  constexpr int PW = RW_PW, PH = RW_PH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int blk = blockIdx.x / a.ksplit, ks = blockIdx.x - blk * a.ksplit;
+  const int per_img = a.tiles_x * a.tiles_y, total = a.B * per_img;
+  // tile sequence: the ksplit/8 workgroups of one XCD (blockIdx % 8) take a contiguous run of each round's tiles (shared halos meet in one L2)
+  const int xcd_n = (a.ksplit & 7) == 0 ? 8 : 1;
+  const int tile0 = (ks % xcd_n) * (a.ksplit / xcd_n) + ks / xcd_n;
+  auto tile_at = [&](int tile) {
+    RwTile t;
+    t.live = tile < total;
+    const int u = t.live ? tile : 0;
+    t.b = u / per_img;
+    const int rem = u - t.b * per_img, ty = rem / a.tiles_x;
+    t.y0 = ty * RW_TH; t.x0 = (rem - ty * a.tiles_x) * RW_TW;
+    return t;
+  };
+
+  if (wave >= 6) {
+    // ================================================================== I/O role: chunk c of slice s = pixels c*8 + r of the haloed tile (row-major)
+    const int r = lane >> 3, ls = (lane & 7) ^ r;
+    const int io = wave - 6;
+    const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
+    const char* X = reinterpret_cast<const char*>(a.x);
+    auto load_tile = [&](const RwTile& t, unsigned buf) {
+#pragma unroll 1
+      for (int c2 = io; c2 < 2 * RW_CH; c2 += 2) {      // 46 chunks over the two I/O waves
+        const int s = c2 >= RW_CH ? 1 : 0, c = c2 - s * RW_CH;
+        const int pix = c * 8 + r;
+        const int py = (pix * 3641) >> 16, px = pix - py * PW;      // pix / 18 for pix < 400
+        const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = s * 64 + ls * 8;
+        const bool ok = t.live && pix < PW * PH && ch < a.cinv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ch) * 2;
+        rw_dma_1k(ok ? src : zero, buf + s * RW_SLICE + c * 1024);
+      }
+    };
+    load_tile(tile_at(tile0), lds_base);
+    int sel = 0;
+    for (int tile = tile0; tile < total; tile += a.ksplit, sel ^= 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's chunks of `tile` have landed
+      __syncthreads();                         // ... and the other I/O wave's; the compute waves are done with buffer sel^1
+      load_tile(tile_at(tile + a.ksplit), lds_base + (sel ^ 1) * RW_BUF);
+    }
+  } else {
+    // ================================================================== compute role: wave = output-channel tile 6*blk + wave
+    const int li = lane & 15, q = lane >> 4;
+    const int cot = blk * 6 + wave;
+    const bool active = cot * 16 < a.n;
+    const int nrow = cot * 16 + li;                  // A rows: this lane's weight row
+    const int c4 = cot * 16 + q * 4;                 // D rows: the 4 output channels this lane stores
+    uint4 wf[9][KC];
+    {
+      const T* Wp = reinterpret_cast<const T*>(a.wp);
+      const T* zw = reinterpret_cast<const T*>(&dd_zero16_v);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int k0 = kc * 32 + q * 8;
+          const bool ok = active && nrow < a.n_pad && k0 < a.k_pad;
+          wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wp + ((long)t * a.n_pad + nrow) * a.k_pad + k0 : zw);
+        }
+    }
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
+    // fragment addresses (32-bit LDS offsets of the CURRENT buffer, flipped by +-RW_BUF per tile): pixel C + li (C = row*18 + dx, a compile-time
+    // constant), K chunk kc = slice kc >> 1, slot (kc & 1)*4 + q  ->  (C + li)*128 + ((slot ^ ((C + li) & 7)) << 4) = d0[C & 7] ^ ((kc & 1) << 6), + C*128
+    unsigned d0[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d0[c] = lds_base + li * DD_LDS_ROW + ((q ^ ((li + c) & 7)) << 4);
+    T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+    const T* __restrict__ M = reinterpret_cast<const T*>(a.mask);
+    const bool ch_ok = active && c4 < a.n;
+    const long yrow = (long)a.W * a.ldy, mrow = (long)a.W * a.ldmask;
+
+    int sel = 0;
+    for (int tile = tile0; tile < total; tile += a.ksplit, sel ^= 1) {
+      __syncthreads();      // the I/O waves' DMA of `tile` has landed (they wait for it before this barrier)
+      if (!active) continue;
+      const RwTile tc = tile_at(tile);
+      const bool col_ok = ch_ok && tc.x0 + li < a.W;
+      const long pix0 = ((long)tc.b * a.H + tc.y0) * a.W + tc.x0 + li;
+      T* yp = Y + pix0 * a.ldy + c4;
+      const T* mp = M + pix0 * a.ldmask + c4;
+      f32x4_t acc[4];      // output rows y % 4: row y is complete after haloed row y + 2, written during haloed row y + 3, re-used by row y + 4
+      uint2 oldv[4], mv[4];
+      constexpr int FR = 3 * KC, NF = PH * FR, RING = 6, AHEAD = RING - 1;      // fragments per haloed row / per tile
+      uint4 ring[RING];
+      auto frag = [&](int f) {
+        const int yy = f / FR, j = f - FR * yy, dx = j / KC, kc = j - KC * dx, C = yy * PW + dx;
+        return rw_lds16((d0[C & 7] ^ ((kc & 1) << 6)) + (kc >> 1) * RW_SLICE + C * DD_LDS_ROW);
+      };
+      auto write_row = [&](int y) {      // ReLU / mask / accumulate, round, store output row y
+        f32x4_t v = acc[y % 4];
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        uint2 o2;
+        o2.x = pack2<T>(v[0], v[1]);
+        o2.y = pack2<T>(v[2], v[3]);
+        if (MASK) { o2.x = mask_bf16x2(o2.x, mv[y % 4].x); o2.y = mask_bf16x2(o2.y, mv[y % 4].y); }
+        if (ACCUM) {
+          float f8[8], g8[8];
+          unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
+          unpack8t<T>(uint4{oldv[y % 4].x, oldv[y % 4].y, 0u, 0u}, g8);
+          o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
+          o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+        }
+        if (col_ok && tc.y0 + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+      };
+#pragma unroll
+      for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
+#pragma unroll
+      for (int yy = 0; yy < PH; ++yy) {
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+          const int f = yy * FR + j, dx = j / KC, kc = j - KC * dx;
+          if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
+          if (j == 0 && yy < RW_TH) {
+            acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
+            const bool ok = col_ok && tc.y0 + yy < a.H;
+            mv[yy % 4] = uint2{0u, 0u}; oldv[yy % 4] = uint2{0u, 0u};
+            if (MASK && ok) mv[yy % 4] = *reinterpret_cast<const uint2*>(mp + yy * mrow);
+            if (ACCUM && ok) oldv[yy % 4] = *reinterpret_cast<const uint2*>(yp + yy * yrow);
+          }
+          if (j == 2 && yy >= 3) write_row(yy - 3);      // (under this row's MFMAs)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int y = yy - dy;
+            if (y >= 0 && y < RW_TH) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], ring[f % RING], acc[y % 4]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      write_row(RW_TH - 1);
+      const int flip = sel ? -RW_BUF : RW_BUF;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d0[c] += flip;
+    }
+  }
+}
+
+static int rw_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename T, int KC, bool MASK, bool ACCUM>
+static void rw_launch(const RwP& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw_kernel<T, KC, MASK, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_rw_kernel<T, KC, MASK, ACCUM>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(512), 2 * (size_t)RW_BUF, stream, p);
+}
+template <typename T, int KC>
+static void rw_launch_flags(const RwP& p, hipStream_t stream) {
+  if (p.mask) { if (p.accum) rw_launch<T, KC, true, true>(p, stream); else rw_launch<T, KC, true, false>(p, stream); }
+  else { if (p.accum) rw_launch<T, KC, false, true>(p, stream); else rw_launch<T, KC, false, false>(p, stream); }
+}
+
+}  // namespace
+
+// Is this dd_conv_igemm call one the register-weight kernel takes?  (3x3, bf16 / f16 storage, 65..96 input channels, plain epilogue)
+bool dd_conv_rw_eligible(const dd_conv_args* a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("DD_CONV_RW"); on = e ? atoi(e) : 1; }
+  if (!on) return false;
+  const int plain = DD_OUT_RELU | DD_ACCUM;
+  return a->taps == 9 && (a->dtype == DD_BF16 || a->dtype == DD_F16) && (a->flags & ~plain) == 0 && !a->res && a->cin > 64 && a->cin <= 96 &&
+         a->k_pad % 32 == 0 && a->k_pad <= 96 && a->n % 4 == 0 && a->ldx % 8 == 0 && a->ldy % 4 == 0 && (!a->mask || a->ldmask % 4 == 0) &&
+         ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0 && (!a->mask || ((uintptr_t)a->mask % 8) == 0);
+}
+
+int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
+  RwP p;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;
+  p.ldx = a->ldx; p.ldmask = a->ldmask; p.ldy = a->ldy;
+  p.cin = a->cin; p.cinv = (a->cin + 7) / 8 * 8; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad; p.nbias = a->nbias;
+  p.B = a->B; p.H = a->H; p.W = a->W;
+  p.tiles_x = dd_ceil_div(a->W, RW_TW); p.tiles_y = dd_ceil_div(a->H, RW_TH);
+  p.nblk = dd_ceil_div(a->n, 96);
+  const long total = (long)a->B * p.tiles_x * p.tiles_y;
+  long ksplit = rw_cus() / p.nblk;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > total) ksplit = total;
+  p.ksplit = (int)ksplit;
+  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
+  if (a->dtype == DD_BF16) rw_launch_flags<bf16_t, 3>(p, stream); else rw_launch_flags<f16_t, 3>(p, stream);
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
