@@ -73,7 +73,11 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
         const int pix = c * 8 + r;
         const int py = (pix * 3641) >> 16, px = pix - py * PW;      // pix / 18 for pix < 400
         const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = s * 64 + ls * 8;
+#ifdef RW_EXP_NO_DMA
+        const bool ok = false;
+#else
         const bool ok = t.live && pix < PW * PH && ch < a.cinv && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+#endif
         const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ch) * 2;
         rw_dma_1k(ok ? src : zero, buf + s * RW_SLICE + c * 1024);
       }
@@ -149,7 +153,11 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
           o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
           o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
         }
+#ifdef RW_EXP_NO_STORE
+        if (col_ok && tc.y0 + y < a.H && o2.x == 0x12345678u) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+#else
         if (col_ok && tc.y0 + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+#endif
       };
 #pragma unroll
       for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
