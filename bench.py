@@ -55,8 +55,12 @@ def measured_traffic(B, dtype):
         except (OSError, ValueError):
             continue
         if m.get("tiles_per_gpu_per_step") == B and m.get("dtype") == dtype and "conv_igemm" in m:
-            c = m["conv_igemm"]
-            return {"bytes_per_launch": 1e6 * (c["fetch_MB_per_launch"] + c["write_MB_per_launch"]), "source": os.path.relpath(path, ROOT)}
+            # the bench's conv_igemm launch family = the LDS-weight kernels plus the register-weight kernel dd_conv_igemm forwards to (PMC lists
+            # them by kernel name): dispatch-weighted mean of the two
+            fams = [m[k] for k in ("conv_igemm", "conv_rw") if k in m]
+            n = sum(c["dispatches"] for c in fams)
+            mb = sum(c["dispatches"] * (c["fetch_MB_per_launch"] + c["write_MB_per_launch"]) for c in fams) / n
+            return {"bytes_per_launch": 1e6 * mb, "source": os.path.relpath(path, ROOT)}
     return None
 
 
