@@ -438,6 +438,27 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
   const long pix = ((long)b * H + (live ? y : 0)) * W + (live ? x : 0);
   T* mine = s_out + threadIdx.x * c_pad;
   for (int c = 0; c < c_pad; ++c) mine[c] = Elem<T>::from_f32(0.f);
+  // The haloed source tile of the NEXT pass is requested (into registers: 2 pixels x 3 channels per thread) while this pass is standardised and
+  // its variance taken from LDS: one exposed memory round trip per tile instead of one per pass (8 passes: 249 -> see DESIGN 3.3).
+  float raw[2][3];
+  auto is_pass = [&](int e) { return e < n_entries && table[t * n_entries + e].nch > 0 && table[t * n_entries + e].kind == 0; };
+  auto request = [&](int e) {
+    const dd_assemble_entry en = table[t * n_entries + e];
+    const int cs = en.cs;
+    const float* img = en.src + (long)b * H * W * cs;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int k = threadIdx.x + it * 256;
+      const int py = k / HP, px = k - py * HP;
+      const int gy = sym_index(min(y0 - 1 + min(py, HP - 1), H), H), gx = sym_index(min(x0 - 1 + px, W), W);
+      const float* sp = img + ((long)gy * W + gx) * cs;
+      if (cs == 3) { raw[it][0] = sp[0]; raw[it][1] = sp[1]; raw[it][2] = sp[2]; }
+      else { raw[it][0] = sp[0]; raw[it][1] = 0.f; raw[it][2] = 0.f; }
+    }
+  };
+  int e_next = 0;
+  while (e_next < n_entries && !is_pass(e_next)) ++e_next;
+  if (e_next < n_entries) request(e_next);
   for (int e = 0; e < n_entries; ++e) {
     const dd_assemble_entry en = table[t * n_entries + e];       // block-uniform
     if (en.nch <= 0) continue;
@@ -452,18 +473,23 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
     }
     const dd_feature_params fp = en.fp;
     const int cs = en.cs;
-    const float* img = en.src + (long)b * H * W * cs;
-    __syncthreads();                                              // the previous entry's staging tiles are consumed
-    for (int k = threadIdx.x; k < HP * HP; k += 256) {
-      const int py = k / HP, px = k - py * HP;
-      const int gy = sym_index(min(y0 - 1 + py, H), H), gx = sym_index(min(x0 - 1 + px, W), W);
-      for (int c = 0; c < cs; ++c) {
-        const float v = img[((long)gy * W + gx) * cs + c];
-        const float sv = standardize(v, fp);
-        s_std[c][py][px] = sv;
-        s_var[c][py][px] = fp.variance_before ? v : sv;
+    __syncthreads();                                              // the previous pass's staging tiles are consumed
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                              // this pass's values (requested one pass ago) -> LDS, standardised
+      const int k = threadIdx.x + it * 256;
+      if (k < HP * HP) {
+        const int py = k / HP, px = k - py * HP;
+        for (int c = 0; c < cs; ++c) {
+          const float v = raw[it][c];
+          const float sv = standardize(v, fp);
+          s_std[c][py][px] = sv;
+          s_var[c][py][px] = fp.variance_before ? v : sv;
+        }
       }
     }
+    e_next = e + 1;
+    while (e_next < n_entries && !is_pass(e_next)) ++e_next;
+    if (e_next < n_entries) request(e_next);                     // in flight during the variance below
     __syncthreads();
     float rec[6];
     rec[0] = s_std[0][ly + 1][lx + 1];
