@@ -164,9 +164,12 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-def test_conv_grad_accumulation_and_concat_views(eng, dtype):
-    """Two consumers of one tensor (the U-Net skip pattern): first writer overwrites, second accumulates; conv writes into a channel range."""
-    B, H, W, f = 2, 16, 16, 32
+@pytest.mark.parametrize("f,H,W", [(32, 16, 16), (96, 20, 12), (80, 9, 33)])
+def test_conv_grad_accumulation_and_concat_views(eng, dtype, f, H, W):
+    """Two consumers of one tensor (the U-Net skip pattern): first writer overwrites, second accumulates; conv writes into a channel range.
+    f = 96 / 80 (bf16 / f16): the data gradients take the register-weight kernel (mask, then mask + accumulate; csrc/dd_conv_rw.hip) and the
+    last layer the fused backward over three 64-channel input blocks (csrc/dd_conv_bwd.hip)."""
+    B = 2
     gen = _gen(7)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, 32, requires_grad=True, relu=True)
