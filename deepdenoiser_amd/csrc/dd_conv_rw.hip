@@ -192,6 +192,142 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------ K <= 64, forward
+// The plain forward (bias, ReLU; no mask, no accumulate, so the waves issue no vector loads of their own) of a layer with <= 64 input channels:
+// 16 x 16 tiles with an 18 x 18 haloed single-slice image (41 KiB x 2 buffers), all 8 waves compute -- wave = one of 4 output-channel tiles x
+// the upper or lower 8 output rows -- and each issues its share of the next tile's 41 DMA chunks between its fragment steps.  Output channels
+// beyond 64 run as further blocks.  This is the data-gradient role of csrc/dd_conv_bwd.hip used as a forward kernel, on all 8 waves.
+constexpr int RF_PW = DD_TILE + 2, RF_CH = (RF_PW * RF_PW + 7) / 8, RF_BUF = RF_CH * 1024;      // 41 chunks
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int PW = RF_PW, KC = 2, RH = DD_TILE / 2, PHW = RH + 2;      // a wave's 8 output rows need 10 haloed rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int blk = blockIdx.x / a.ksplit, ks = blockIdx.x - blk * a.ksplit;
+  const int per_img = a.tiles_x * a.tiles_y, total = a.B * per_img;
+  const int xcd_n = (a.ksplit & 7) == 0 ? 8 : 1;
+  const int tile0 = (ks % xcd_n) * (a.ksplit / xcd_n) + ks / xcd_n;
+  auto tile_at = [&](int tile) {
+    RwTile t;
+    t.live = tile < total;
+    const int u = t.live ? tile : 0;
+    t.b = u / per_img;
+    const int rem = u - t.b * per_img, ty = rem / a.tiles_x;
+    t.y0 = ty * DD_TILE; t.x0 = (rem - ty * a.tiles_x) * DD_TILE;
+    return t;
+  };
+  // ---- DMA: chunk c = k*8 + wave (k < 6, c < 41) = pixels c*8 + r of the haloed tile
+  const int r = lane >> 3, ls = (lane & 7) ^ r;
+  const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
+  const char* X = reinterpret_cast<const char*>(a.x);
+  const bool ch_in = ls * 8 < a.cinv;
+  auto piece = [&](int k, const RwTile& t, unsigned buf) {
+    const int c = k * 8 + wave;
+    if (c < RF_CH) {      // wave-uniform
+      int rr = r;
+      asm volatile("" : "+v"(rr));      // (keeps the per-piece coordinates from being hoisted out of the tile loop: see csrc/dd_conv_bwd.hip)
+      const int pix = c * 8 + rr;
+      const int py = (pix * 3641) >> 16, px = pix - py * PW;
+      const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px;
+      const bool ok = t.live && ch_in && pix < PW * PW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ls * 8) * 2;
+      rw_dma_1k(ok ? src : zero, buf + c * 1024);
+    }
+  };
+  RwTile cur = tile_at(tile0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) piece(k, cur, lds_base);
+
+  // ---- compute: output-channel tile (wave & 3) of block blk, output rows 8*(wave >> 2) .. + 7
+  const int li = lane & 15, q = lane >> 4;
+  const int cot = blk * 4 + (wave & 3), half = wave >> 2;
+  const bool active = cot * 16 < a.n;
+  const int nrow = cot * 16 + li, c4 = cot * 16 + q * 4;
+  uint4 wf[9][KC];
+  {
+    const T* Wp = reinterpret_cast<const T*>(a.wp);
+    const T* zw = reinterpret_cast<const T*>(&dd_zero16_v);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int k0 = kc * 32 + q * 8;
+        const bool ok = active && nrow < a.n_pad && k0 < a.k_pad;
+        wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wp + ((long)t * a.n_pad + nrow) * a.k_pad + k0 : zw);
+      }
+  }
+  float bv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bv[e] = (a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
+  unsigned d0[8];      // haloed pixel (8*half + yy)*18 + dx + li: the row offset of the half is folded into the bases
+#pragma unroll
+  for (int c = 0; c < 8; ++c) d0[c] = lds_base + (half * RH * PW + li) * DD_LDS_ROW + ((q ^ ((half * RH * PW + li + c) & 7)) << 4);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const bool ch_ok = active && c4 < a.n;
+  const long yrow = (long)a.W * a.ldy;
+
+  int sel = 0;
+  for (int tile = tile0; tile < total; tile += a.ksplit, sel ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's chunks of `tile` have landed (and its stores of the previous one)
+    __syncthreads();
+    const RwTile nxt = tile_at(tile + a.ksplit);
+    const unsigned nbuf = lds_base + (sel ^ 1) * RF_BUF;
+    if (!active) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) piece(k, nxt, nbuf);
+      cur = nxt;
+      continue;
+    }
+    const bool col_ok = ch_ok && cur.x0 + li < a.W;
+    T* yp = Y + (((long)cur.b * a.H + cur.y0 + half * RH) * a.W + cur.x0 + li) * a.ldy + c4;
+    f32x4_t acc[4];
+    constexpr int FR = 3 * KC, NF = PHW * FR, RING = 6, AHEAD = RING - 1;
+    uint4 ring[RING];
+    auto frag = [&](int f) {
+      const int yy = f / FR, j = f - FR * yy, dx = j / KC, kc = j - KC * dx, C = yy * PW + dx;
+      return rw_lds16((d0[C & 7] ^ (kc << 6)) + C * DD_LDS_ROW);
+    };
+    auto write_row = [&](int y) {
+      f32x4_t v = acc[y % 4];
+      if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      uint2 o2;
+      o2.x = pack2<T>(v[0], v[1]);
+      o2.y = pack2<T>(v[2], v[3]);
+      if (col_ok && cur.y0 + half * RH + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+    };
+#pragma unroll
+    for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
+#pragma unroll
+    for (int yy = 0; yy < PHW; ++yy) {
+#pragma unroll
+      for (int j = 0; j < FR; ++j) {
+        const int f = yy * FR + j, dx = j / KC, kc = j - KC * dx;
+        if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
+        if (j == 0 && yy < RH) acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
+        if (j == 2 && yy >= 3) write_row(yy - 3);
+        {      // the 6 DMA pieces of the next tile, spread evenly over the NF steps
+          const int k0 = (f * 6 + NF - 1) / NF;
+          if (k0 < 6 && (k0 * NF) / 6 == f) piece(k0, nxt, nbuf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int y = yy - dy;
+          if (y >= 0 && y < RH) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], ring[f % RING], acc[y % 4]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    write_row(RH - 1);
+    const int flip = sel ? -RF_BUF : RF_BUF;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d0[c] += flip;
+    cur = nxt;
+  }
+}
+
 static int rw_cus() {
   static int n = 0;
   if (n == 0) {
@@ -219,15 +355,20 @@ static void rw_launch_flags(const RwP& p, hipStream_t stream) {
 
 }  // namespace
 
-// Is this dd_conv_igemm call one the register-weight kernel takes?  (3x3, bf16 / f16 storage, 65..96 input channels, plain epilogue)
+// Is this dd_conv_igemm call one the register-weight kernels take?  3x3, bf16 / f16 storage, plain epilogue, and either 65..96 input channels
+// (any epilogue of {ReLU, mask, accumulate}) or <= 64 input channels with nothing but bias / ReLU (the forward of the 64-channel level)
 bool dd_conv_rw_eligible(const dd_conv_args* a) {
-  static int on = -1;
+  static int on = -1, on8 = -1;
   if (on < 0) { const char* e = getenv("DD_CONV_RW"); on = e ? atoi(e) : 1; }
+  if (on8 < 0) { const char* e = getenv("DD_CONV_RW8"); on8 = e ? atoi(e) : 1; }
   if (!on) return false;
   const int plain = DD_OUT_RELU | DD_ACCUM;
-  return a->taps == 9 && (a->dtype == DD_BF16 || a->dtype == DD_F16) && (a->flags & ~plain) == 0 && !a->res && a->cin > 64 && a->cin <= 96 &&
-         a->k_pad % 32 == 0 && a->k_pad <= 96 && a->n % 4 == 0 && a->ldx % 8 == 0 && a->ldy % 4 == 0 && (!a->mask || a->ldmask % 4 == 0) &&
-         ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0 && (!a->mask || ((uintptr_t)a->mask % 8) == 0);
+  const bool common = a->taps == 9 && (a->dtype == DD_BF16 || a->dtype == DD_F16) && (a->flags & ~plain) == 0 && !a->res && a->k_pad % 32 == 0 &&
+                      a->n % 4 == 0 && a->ldx % 8 == 0 && a->ldy % 4 == 0 && (!a->mask || a->ldmask % 4 == 0) && ((uintptr_t)a->x % 16) == 0 &&
+                      ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0 && (!a->mask || ((uintptr_t)a->mask % 8) == 0);
+  if (!common) return false;
+  if (a->cin > 64 && a->cin <= 96 && a->k_pad <= 96) return true;
+  return on8 && a->cin > 16 && a->cin <= 64 && a->k_pad <= 64 && !a->mask && !(a->flags & DD_ACCUM) && a->n >= 48;
 }
 
 int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
@@ -236,15 +377,28 @@ int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
   p.ldx = a->ldx; p.ldmask = a->ldmask; p.ldy = a->ldy;
   p.cin = a->cin; p.cinv = (a->cin + 7) / 8 * 8; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad; p.nbias = a->nbias;
   p.B = a->B; p.H = a->H; p.W = a->W;
-  p.tiles_x = dd_ceil_div(a->W, RW_TW); p.tiles_y = dd_ceil_div(a->H, RW_TH);
-  p.nblk = dd_ceil_div(a->n, 96);
+  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
+  const bool wide_k = a->cin > 64;
+  p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, wide_k ? RW_TH : DD_TILE);
+  p.nblk = dd_ceil_div(a->n, wide_k ? 96 : 64);
   const long total = (long)a->B * p.tiles_x * p.tiles_y;
   long ksplit = rw_cus() / p.nblk;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > total) ksplit = total;
   p.ksplit = (int)ksplit;
-  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
-  if (a->dtype == DD_BF16) rw_launch_flags<bf16_t, 3>(p, stream); else rw_launch_flags<f16_t, 3>(p, stream);
+  if (wide_k) {
+    if (a->dtype == DD_BF16) rw_launch_flags<bf16_t, 3>(p, stream); else rw_launch_flags<f16_t, 3>(p, stream);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    const dim3 grid((unsigned)(p.nblk * p.ksplit));
+    if (a->dtype == DD_BF16) hipLaunchKernelGGL(conv_rw8_kernel<bf16_t>, grid, dim3(512), 2 * (size_t)RF_BUF, stream, p);
+    else hipLaunchKernelGGL(conv_rw8_kernel<f16_t>, grid, dim3(512), 2 * (size_t)RF_BUF, stream, p);
+  }
   DD_LAUNCH_CHECK();
   return DD_OK;
 }
