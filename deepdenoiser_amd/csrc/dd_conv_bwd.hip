@@ -347,7 +347,11 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ci = cb * 64 + i * 16 + q4 + e;
+#ifdef CBW_EXP_NO_FLUSH
+              if (ci < a.cin && acc[t][i][e] == 123.456f) atomicAdd(a.dw + ((long)(8 - t) * a.cin + ci) * a.cout + co, acc[t][i][e]);
+#else
               if (ci < a.cin) atomicAdd(a.dw + ((long)(8 - t) * a.cin + ci) * a.cout + co, acc[t][i][e]);
+#endif
             }
           }
       }
