@@ -205,7 +205,10 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       uint2 oldv[4], mv[4];
       // 108 fragment steps = 18 haloed rows x 3 column shifts x 2 K-chunks, up to 3 MFMAs each (the output rows yy, yy-1, yy-2).  Fragments are
       // requested AHEAD steps before use; sched_barriers keep that order (left alone hipcc waits for each read right before its MFMAs).
-      constexpr int RING = 6, AHEAD = RING - 1, NF = PW * 6;
+#ifndef CBW_RING
+#define CBW_RING 6
+#endif
+      constexpr int RING = CBW_RING, AHEAD = RING - 1, NF = PW * 6;
       uint4 ring[RING];
       auto frag = [&](int f) {
         const int yy = f / 6, j = f - 6 * yy, C = yy * PW + (j >> 1);
@@ -251,7 +254,9 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
             const int y = yy - dy;
             if (y >= 0 && y < DD_TILE) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], ring[f % RING], acc[y % 4]);
           }
+#ifndef CBW_EXP_ONE_BARRIER
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
       write_row(DD_TILE - 1);
@@ -325,7 +330,9 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
           unpack8t<T>(df[step & 1], f);
           bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
+#ifndef CBW_EXP_ONE_BARRIER_W
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       // the other buffer next time
       const int flip = sel ? -BW_BUF : BW_BUF;
