@@ -89,7 +89,13 @@ template <> __device__ __forceinline__ uint4 relu16<float>(uint4 v) {
   v.w = __float_as_uint(fmaxf(__uint_as_float(v.w), 0.f));
   return v;
 }
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) { return w & ~(((w >> 15) & 0x10001u) * 0xffffu); }
+// relu on two packed bf16 / fp16 values: as 16-bit integers a negative float (sign bit set) is a negative integer and a non-negative one keeps
+// its order, so max(., 0) per half IS relu (-0.0 -> +0.0): one v_pk_max_i16 instead of four bit operations per word
+typedef short dd_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
+  const dd_s16x2 v = __builtin_bit_cast(dd_s16x2, w), z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
+}
 template <> __device__ __forceinline__ uint4 relu16<bf16_t>(uint4 v) {
   v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w);
   return v;
@@ -158,9 +164,12 @@ template <> __device__ __forceinline__ uint4 pack8t<f16_t>(const float (&v)[8]) 
 }
 // keep the bf16 / fp16 lanes of `v` whose mask lane is > 0 (sign bit clear and not zero: the same test in both formats) (ReLU-backward on packed data, no unpacking)
 __device__ __forceinline__ uint32_t mask_bf16x2(uint32_t v, uint32_t m) {
-  const uint32_t lo = ((m & 0x8000u) == 0u && (m & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
-  const uint32_t hi = ((m & 0x80000000u) == 0u && (m & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
-  return v & (lo | hi);
+  // m > 0 as a float <=> m > 0 as a 16-bit integer (sign clear, not zero).  0 - m (saturating: -(-32768) must not wrap) is negative exactly
+  // then; its arithmetic shift by 15 is the 0xffff / 0 keep mask of the half: three packed instructions per word
+  const dd_s16x2 mm = __builtin_bit_cast(dd_s16x2, m), z = {0, 0};
+  const dd_s16x2 neg = __builtin_elementwise_sub_sat(z, mm);
+  const dd_s16x2 keep = neg >> 15;
+  return v & __builtin_bit_cast(uint32_t, keep);
 }
 __device__ __forceinline__ uint4 mask_bf16x8(uint4 v, uint4 m) {
   v.x = mask_bf16x2(v.x, m.x); v.y = mask_bf16x2(v.y, m.y); v.z = mask_bf16x2(v.z, m.z); v.w = mask_bf16x2(v.w, m.w);

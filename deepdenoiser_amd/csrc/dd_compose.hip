@@ -134,12 +134,12 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const char
         float r[4];
         load4<T>(reinterpret_cast<const T*>(res + (fy * FR + fx) * PIXB) + ch, r);
         a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3];
-      } else {
-        a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f);
       }
-      uint2 pk;
-      pk.x = inside ? pack2<T>(a[0], a[1]) : 0u;       // TensorFlow pads every conv's input with zeros: nothing exists outside the image
-      pk.y = inside ? pack2<T>(a[2], a[3]) : 0u;
+      uint2 pk;                                          // (ReLU on the packed result: one v_pk_max_i16 per word instead of two v_max_f32 per value)
+      pk.x = pack2<T>(a[0], a[1]); pk.y = pack2<T>(a[2], a[3]);
+      if (!RESIDUAL) { pk.x = relu_bf16x2(pk.x); pk.y = relu_bf16x2(pk.y); }
+      pk.x = inside ? pk.x : 0u;                         // TensorFlow pads every conv's input with zeros: nothing exists outside the image
+      pk.y = inside ? pk.y : 0u;
       if (P < NPIX) *reinterpret_cast<uint2*>(o + ch * 2) = pk;
     }
   }
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
           const f32x4_t w = *reinterpret_cast<const f32x4_t*>(w_in + k * 24 + n4 * 4);
           a[0] += x[k] * w[0]; a[1] += x[k] * w[1]; a[2] += x[k] * w[2]; a[3] += x[k] * w[3];
         }
-        const uint32_t lo = inside ? pack2<T>(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)) : 0u;
-        const uint32_t hi = inside ? pack2<T>(fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)) : 0u;
+        const uint32_t lo = inside ? relu_bf16x2(pack2<T>(a[0], a[1])) : 0u;
+        const uint32_t hi = inside ? relu_bf16x2(pack2<T>(a[2], a[3])) : 0u;
         uint32_t* ow = reinterpret_cast<uint32_t*>(&o[n4 >> 1]) + (n4 & 1) * 2;
         ow[0] = lo; ow[1] = hi;
       }
