@@ -461,31 +461,37 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
         for (int e = 0; e < 4; ++e) dlv[j * 4 + e] = p[j][e] * (dp[j][e] - dot);
       const uint4 dl = pack8t<T>(dlv);                 // stored in the storage type by the layer-wise path: round here too
       // GEMM 3 + ReLU mask of hid -> d hid (pre-activation), as the k-group of GEMM 4
-      float hv[8], dhv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      unpack8t<T>(hid, hv);
+      // (the ReLU masks are applied to the PACKED results with 16-bit integer ops -- mask_bf16x2: 3 instructions per word -- instead of unpacking
+      //  the mask, comparing and selecting per value: the loop is bound by its VALU instruction count)
+      float dhv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma16<T>(a3[j], dl, acc);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dhv[j * 4 + e] = hv[j * 4 + e] > 0.f ? acc[e] : 0.f;
+        for (int e = 0; e < 4; ++e) dhv[j * 4 + e] = acc[e];
       }
-      const uint4 dh = pack8t<T>(dhv);
+      const uint4 dh = mask_bf16x8(pack8t<T>(dhv), hid);
       // GEMM 4 -> d x, masked by x > 0 (x is a ReLU output of the backbone), optionally accumulated into an existing gradient
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int c = ct * 16 + q * 4;
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma16<T>(s_a4[ct * 64], dh, acc);
-        float m8[8], o8[8], v[4];
-        unpack8t<T>(uint4{xm[ct].x, xm[ct].y, 0u, 0u}, m8);
-        unpack8t<T>(uint4{old[ct].x, old[ct].y, 0u, 0u}, o8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = Elem<T>::to_f32(Elem<T>::from_f32(m8[e] > 0.f ? acc[e] : 0.f)) + o8[e];
+        uint2 o2;
+        o2.x = mask_bf16x2(pack2<T>(acc[0], acc[1]), xm[ct].x);
+        o2.y = mask_bf16x2(pack2<T>(acc[2], acc[3]), xm[ct].y);
+        if (a.accumulate) {
+          float f8[8], g8[8];
+          unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
+          unpack8t<T>(uint4{old[ct].x, old[ct].y, 0u, 0u}, g8);
+          o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
+          o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+        }
 #ifndef HB_EXP_NO_DX
-        if (pa.ok && c < a.C) store4<T>(dxp + c, v);
+        if (pa.ok && c < a.C) *reinterpret_cast<uint2*>(dxp + c) = o2;
 #else
-        if (v[0] == 123.456f) store4<T>(dxp + c, v);
+        if (o2.x == 0x12345678u) *reinterpret_cast<uint2*>(dxp + c) = o2;
 #endif
       }
       // park this pixel's operands of the weight gradients (zero rows for pixels past the end)

@@ -62,3 +62,19 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu 
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     mirror = [ctypes.sizeof(t) for t in (_lib.ConvTArgs, _lib.ConvBwdArgs, _lib.AssembleEntry, _lib.HeadArgs, _lib.ComposeBwdArgs, _lib.ComposeArgs, _lib.ConvArgs, _lib.WgradArgs, _lib.FeatureParams, _lib.GatherEntry, _lib.LossDesc, _lib.StitchEntry, _lib.RecombineDesc, _lib.PackDesc, _lib.AugmentDraw)]
     assert sizes == mirror
+
+
+def test_build_refuses_scratch_in_kernels_with_inplace_asm_accumulators():
+    """deepdenoiser_amd/build.py: the kernels whose accumulators are updated by in-place inline-asm MFMAs are only correct without spills; the
+    build parses hipcc's resource-usage remarks and refuses a non-zero ScratchSize."""
+    import pytest
+    from deepdenoiser_amd import build
+    ok = ("x.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_115conv_bwd_kernelItLb1ELb0EEEvNS_4BwdPE [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.hip:1:1: remark:     VGPRs: 210 [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    build._check_no_scratch("dd_conv_bwd.hip", ("conv_bwd_kernel",), ok)
+    with pytest.raises(RuntimeError, match="scratch"):
+        build._check_no_scratch("dd_conv_bwd.hip", ("conv_bwd_kernel",), ok.replace("lane]: 0", "lane]: 48"))
+    with pytest.raises(RuntimeError, match="no resource-usage remark"):
+        build._check_no_scratch("dd_conv_bwd.hip", ("conv_bwd_kernel",), "nothing here")
+    assert set(build.NO_SCRATCH) <= set(build.SOURCES)
