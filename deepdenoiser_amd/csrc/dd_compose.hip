@@ -169,6 +169,22 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
   }
   __syncthreads();
 
+  // layer 0 on the matrix pipe: this lane's A row = output channel j*16 + li, its 6 input weights as one 8-element k-group; bias of the 4
+  // channels (j*16 + q*4 ..) it receives
+  static_assert(FR * FR % 64 == 0, "layer 0 works on whole waves");
+  uint4 w0a, w0b;
+  float bias0[8];
+  {
+    float w[2][6];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[j][k] = j * 16 + li < 24 ? w_in[k * 24 + j * 16 + li] : 0.f;
+    w0a = uint4{pack2<T>(w[0][0], w[0][1]), pack2<T>(w[0][2], w[0][3]), pack2<T>(w[0][4], w[0][5]), 0u};
+    w0b = uint4{pack2<T>(w[1][0], w[1][1]), pack2<T>(w[1][2], w[1][3]), pack2<T>(w[1][4], w[1][5]), 0u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias0[e] = b_in[q * 4 + e]; bias0[4 + e] = q < 2 ? b_in[16 + q * 4 + e] : 0.f; }
+  }
   const int per_img = p.tiles_y * p.tiles_x;
   const int H = p.H, W = p.W, h2 = H >> 1, w2 = W >> 1;
   // The net input of the NEXT tile (6 fp32 values for each of this thread's 1-2 frame pixels) is requested while the current tile's four
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int idx = tid + i * 512;
-      if (idx >= FR * FR) continue;
+      if (wave * 64 + i * 512 >= FR * FR) continue;      // whole waves: 576 = 9 x 64 frame pixels, the MFMAs below need all 64 lanes
       const int fy = idx / FR, fx = idx - fy * FR;
       const int gy = y0 - 4 + fy, gx = x0 - 4 + fx;
       const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -222,26 +238,30 @@ __global__ __launch_bounds__(512) void compose_fwd_kernel(const ComposeP p) {
           *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.save_netin) + (((long)b * H + gy) * W + gx) * p.ld_netin * 2) = v;
         }
       }
-      // every intermediate is rounded to the storage type where the layer-wise path stores it (here: the packed 6-channel net input),
-      // so the two paths differ only in the fp32 summation order inside the MFMAs
+      // The 1x1 on the matrix pipe.  Every lane holds ITS pixel's 6 inputs (rounded to the storage type, where the layer-wise path stores the
+      // packed net input) as the 8-element k-group of an MFMA B operand; with the weights placed in k-group g of the A operand and zeros in the
+      // other three, one MFMA is the layer for the 16 pixels held by the lanes of group g: 4 groups x 2 channel tiles = 8 MFMAs per 64
+      // pixels, results as [4 channels][pixel] per lane.  (As 144 FMAs per pixel on the VALU this layer was 4.7 k of a tile's 29 k cycles
+      // in a kernel bound by its VALU work.)
+      const uint4 bx = {pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]), pack2<T>(x[4], x[5]), 0u};
+      const unsigned long long in_mask = __ballot(inside);
+      const uint4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int k = 0; k < 6; ++k) x[k] = Elem<T>::to_f32(Elem<T>::from_f32(x[k]));
-      uint4 o[3];
-#pragma unroll
-      for (int n4 = 0; n4 < 6; ++n4) {
-        f32x4_t a = *reinterpret_cast<const f32x4_t*>(b_in + n4 * 4);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const f32x4_t w = *reinterpret_cast<const f32x4_t*>(w_in + k * 24 + n4 * 4);
-          a[0] += x[k] * w[0]; a[1] += x[k] * w[1]; a[2] += x[k] * w[2]; a[3] += x[k] * w[3];
-        }
-        const uint32_t lo = inside ? relu_bf16x2(pack2<T>(a[0], a[1])) : 0u;
-        const uint32_t hi = inside ? relu_bf16x2(pack2<T>(a[2], a[3])) : 0u;
-        uint32_t* ow = reinterpret_cast<uint32_t*>(&o[n4 >> 1]) + (n4 & 1) * 2;
-        ow[0] = lo; ow[1] = hi;
+      for (int g = 0; g < 4; ++g) {
+        const uint4 wa = q == g ? w0a : z4, wb = q == g ? w0b : z4;
+        const f32x4_t d0 = mma16<T>(wa, bx, f32x4_t{bias0[0], bias0[1], bias0[2], bias0[3]});
+        const f32x4_t d1 = mma16<T>(wb, bx, f32x4_t{bias0[4], bias0[5], bias0[6], bias0[7]});
+        const int pl = g * 16 + li;                        // the pixel these results belong to: lane pl of this wave
+        const bool ins = (in_mask >> pl) & 1ull;
+        char* dst = bufA + (idx - lane + pl) * PIXB;
+        uint2 o0, o1;
+        o0.x = ins ? relu_bf16x2(pack2<T>(d0[0], d0[1])) : 0u;
+        o0.y = ins ? relu_bf16x2(pack2<T>(d0[2], d0[3])) : 0u;
+        o1.x = ins ? relu_bf16x2(pack2<T>(d1[0], d1[1])) : 0u;
+        o1.y = ins ? relu_bf16x2(pack2<T>(d1[2], d1[3])) : 0u;
+        *reinterpret_cast<uint2*>(dst + q * 8) = o0;                          // channels q*4 .. q*4+3
+        if (q < 2) *reinterpret_cast<uint2*>(dst + 32 + q * 8) = o1;          // channels 16 + q*4 ..
       }
-      uint4* dst = reinterpret_cast<uint4*>(bufA + idx * PIXB);
-      dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
     CPH(1);
     __syncthreads();
