@@ -197,12 +197,18 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
 // 16 x 16 tiles with an 18 x 18 haloed single-slice image (41 KiB x 2 buffers), all 8 waves compute -- wave = one of 4 output-channel tiles x
 // the upper or lower 8 output rows -- and each issues its share of the next tile's 41 DMA chunks between its fragment steps.  Output channels
 // beyond 64 run as further blocks.  This is the data-gradient role of csrc/dd_conv_bwd.hip used as a forward kernel, on all 8 waves.
-constexpr int RF_PW = DD_TILE + 2, RF_CH = (RF_PW * RF_PW + 7) / 8, RF_BUF = RF_CH * 1024;      // 41 chunks
+// KC = 2: <= 64 input channels, one 64-channel slice, 16 x 16 tiles (18 x 18 haloed: 41 chunks);  KC = 4: <= 128 input channels, two slices,
+// 16 x 8 tiles (18 x 10 haloed: 2 x 23 chunks) -- either way <= 46 KiB per buffer
+template <int KC> struct RfGeo {
+  static constexpr int NS = (KC + 1) / 2, TH = NS == 1 ? DD_TILE : DD_TILE / 2, PW = DD_TILE + 2, PH = TH + 2;
+  static constexpr int CH = (PW * PH + 7) / 8, SLICE = CH * 1024, BUF = NS * SLICE, NCHUNK = NS * CH, NPIECE = (NCHUNK + 7) / 8;
+};
 
-template <typename T>
+template <typename T, int KC>
 __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  constexpr int PW = RF_PW, KC = 2, RH = DD_TILE / 2, PHW = RH + 2;      // a wave's 8 output rows need 10 haloed rows
+  using G = RfGeo<KC>;
+  constexpr int PW = G::PW, RH = G::TH / 2, PHW = RH + 2;      // a wave's RH output rows need RH + 2 haloed rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int blk = blockIdx.x / a.ksplit, ks = blockIdx.x - blk * a.ksplit;
@@ -215,32 +221,32 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
     const int u = t.live ? tile : 0;
     t.b = u / per_img;
     const int rem = u - t.b * per_img, ty = rem / a.tiles_x;
-    t.y0 = ty * DD_TILE; t.x0 = (rem - ty * a.tiles_x) * DD_TILE;
+    t.y0 = ty * G::TH; t.x0 = (rem - ty * a.tiles_x) * DD_TILE;
     return t;
   };
-  // ---- DMA: chunk c = k*8 + wave (k < 6, c < 41) = pixels c*8 + r of the haloed tile
+  // ---- DMA: chunk id = k*8 + wave (< NS * CH): slice id / CH, pixels (id % CH)*8 + r of the haloed tile
   const int r = lane >> 3, ls = (lane & 7) ^ r;
   const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
   const char* X = reinterpret_cast<const char*>(a.x);
-  const bool ch_in = ls * 8 < a.cinv;
   auto piece = [&](int k, const RwTile& t, unsigned buf) {
-    const int c = k * 8 + wave;
-    if (c < RF_CH) {      // wave-uniform
+    const int id = k * 8 + wave;
+    if (id < G::NCHUNK) {      // wave-uniform
       int rr = r;
       asm volatile("" : "+v"(rr));      // (keeps the per-piece coordinates from being hoisted out of the tile loop: see csrc/dd_conv_bwd.hip)
+      const int sl = id >= G::CH ? 1 : 0, c = id - sl * G::CH;
       const int pix = c * 8 + rr;
       const int py = (pix * 3641) >> 16, px = pix - py * PW;
-      const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px;
-      const bool ok = t.live && ch_in && pix < PW * PW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ls * 8) * 2;
-      rw_dma_1k(ok ? src : zero, buf + c * 1024);
+      const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = sl * 64 + ls * 8;
+      const bool ok = t.live && ch < a.cinv && pix < PW * G::PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ch) * 2;
+      rw_dma_1k(ok ? src : zero, buf + sl * G::SLICE + c * 1024);
     }
   };
   RwTile cur = tile_at(tile0);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) piece(k, cur, lds_base);
+  for (int k = 0; k < G::NPIECE; ++k) piece(k, cur, lds_base);
 
-  // ---- compute: output-channel tile (wave & 3) of block blk, output rows 8*(wave >> 2) .. + 7
+  // ---- compute: output-channel tile (wave & 3) of block blk, output rows RH*(wave >> 2) .. + RH - 1
   const int li = lane & 15, q = lane >> 4;
   const int cot = blk * 4 + (wave & 3), half = wave >> 2;
   const bool active = cot * 16 < a.n;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
   float bv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) bv[e] = (a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
-  unsigned d0[8];      // haloed pixel (8*half + yy)*18 + dx + li: the row offset of the half is folded into the bases
+  unsigned d0[8];      // haloed pixel (RH*half + yy)*18 + dx + li: the row offset of the half is folded into the bases
 #pragma unroll
   for (int c = 0; c < 8; ++c) d0[c] = lds_base + (half * RH * PW + li) * DD_LDS_ROW + ((q ^ ((half * RH * PW + li + c) & 7)) << 4);
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
@@ -273,10 +279,10 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's chunks of `tile` have landed (and its stores of the previous one)
     __syncthreads();
     const RwTile nxt = tile_at(tile + a.ksplit);
-    const unsigned nbuf = lds_base + (sel ^ 1) * RF_BUF;
+    const unsigned nbuf = lds_base + (sel ^ 1) * G::BUF;
     if (!active) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) piece(k, nxt, nbuf);
+      for (int k = 0; k < G::NPIECE; ++k) piece(k, nxt, nbuf);
       cur = nxt;
       continue;
     }
@@ -287,14 +293,14 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
     uint4 ring[RING];
     auto frag = [&](int f) {
       const int yy = f / FR, j = f - FR * yy, dx = j / KC, kc = j - KC * dx, C = yy * PW + dx;
-      return rw_lds16((d0[C & 7] ^ (kc << 6)) + C * DD_LDS_ROW);
+      return rw_lds16((d0[C & 7] ^ ((kc & 1) << 6)) + (kc >> 1) * G::SLICE + C * DD_LDS_ROW);
     };
     auto write_row = [&](int y) {
       f32x4_t v = acc[y % 4];
-      if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       uint2 o2;
       o2.x = pack2<T>(v[0], v[1]);
       o2.y = pack2<T>(v[2], v[3]);
+      if (a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
       if (col_ok && cur.y0 + half * RH + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
     };
 #pragma unroll
@@ -307,9 +313,9 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
         if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
         if (j == 0 && yy < RH) acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
         if (j == 2 && yy >= 3) write_row(yy - 3);
-        {      // the 6 DMA pieces of the next tile, spread evenly over the NF steps
-          const int k0 = (f * 6 + NF - 1) / NF;
-          if (k0 < 6 && (k0 * NF) / 6 == f) piece(k0, nxt, nbuf);
+        {      // the DMA pieces of the next tile, spread evenly over the NF steps
+          const int k0 = (f * G::NPIECE + NF - 1) / NF;
+          if (k0 < G::NPIECE && (k0 * NF) / G::NPIECE == f) piece(k0, nxt, nbuf);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -320,8 +326,9 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    write_row(RH - 1);
-    const int flip = sel ? -RF_BUF : RF_BUF;
+#pragma unroll
+    for (int y = (PHW >= 3 ? PHW - 3 : 0); y < RH; ++y) write_row(y);      // the rows completed by the last haloed rows
+    const int flip = sel ? -G::BUF : G::BUF;
 #pragma unroll
     for (int c = 0; c < 8; ++c) d0[c] += flip;
     cur = nxt;
@@ -368,7 +375,19 @@ bool dd_conv_rw_eligible(const dd_conv_args* a) {
                       ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0 && (!a->mask || ((uintptr_t)a->mask % 8) == 0);
   if (!common) return false;
   if (a->cin > 64 && a->cin <= 96 && a->k_pad <= 96) return true;
-  return on8 && a->cin > 16 && a->cin <= 64 && a->k_pad <= 64 && !a->mask && !(a->flags & DD_ACCUM) && a->n >= 48;
+  // forward on all 8 waves: <= 64 input channels, or 97..128 (two slices, weights 144 registers); nothing but bias / ReLU in the epilogue
+  return on8 && ((a->cin > 16 && a->cin <= 64 && a->k_pad <= 64) || (a->cin > 96 && a->cin <= 128 && a->k_pad <= 128)) && !a->mask &&
+         !(a->flags & DD_ACCUM) && a->n >= 48;
+}
+
+template <typename T, int KC>
+static void rw8_launch(const RwP& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_rw8_kernel<T, KC>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(512), 2 * (size_t)RfGeo<KC>::BUF, stream, p);
 }
 
 int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
@@ -378,26 +397,21 @@ int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
   p.cin = a->cin; p.cinv = (a->cin + 7) / 8 * 8; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad; p.nbias = a->nbias;
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
-  const bool wide_k = a->cin > 64;
-  p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, wide_k ? RW_TH : DD_TILE);
-  p.nblk = dd_ceil_div(a->n, wide_k ? 96 : 64);
+  const bool six = a->cin > 64 && a->cin <= 96;      // 6 compute + 2 I/O waves, any epilogue; else all 8 waves, forward only
+  const int th = six ? RW_TH : (a->cin <= 64 ? RfGeo<2>::TH : RfGeo<4>::TH);
+  p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, th);
+  p.nblk = dd_ceil_div(a->n, six ? 96 : 64);
   const long total = (long)a->B * p.tiles_x * p.tiles_y;
   long ksplit = rw_cus() / p.nblk;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > total) ksplit = total;
   p.ksplit = (int)ksplit;
-  if (wide_k) {
+  if (six) {
     if (a->dtype == DD_BF16) rw_launch_flags<bf16_t, 3>(p, stream); else rw_launch_flags<f16_t, 3>(p, stream);
+  } else if (a->cin <= 64) {
+    if (a->dtype == DD_BF16) rw8_launch<bf16_t, 2>(p, stream); else rw8_launch<f16_t, 2>(p, stream);
   } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    const dim3 grid((unsigned)(p.nblk * p.ksplit));
-    if (a->dtype == DD_BF16) hipLaunchKernelGGL(conv_rw8_kernel<bf16_t>, grid, dim3(512), 2 * (size_t)RF_BUF, stream, p);
-    else hipLaunchKernelGGL(conv_rw8_kernel<f16_t>, grid, dim3(512), 2 * (size_t)RF_BUF, stream, p);
+    if (a->dtype == DD_BF16) rw8_launch<bf16_t, 4>(p, stream); else rw8_launch<f16_t, 4>(p, stream);
   }
   DD_LAUNCH_CHECK();
   return DD_OK;
