@@ -77,10 +77,13 @@ def test_cfg3_full_size_forward_parity_f32():
     print("cfg-3 256x256 f32 forward worst rel-L2: %.2e" % worst)
 
 
-@pytest.mark.parametrize("dtype,fwd_tol,grad_median_tol", [("bf16", 1e-2, 0.055), ("f16", 1.2e-3, 0.01)])
+@pytest.mark.parametrize("dtype,fwd_tol,grad_median_tol", [("bf16", 1e-2, 0.045), ("f16", 1.2e-3, 0.016)])
 def test_half_precision_storage_reports_its_tolerance_at_full_size(dtype, fwd_tol, grad_median_tol):
     """bf16 (training throughput path) and fp16 (inference path) storage against the f64 oracle, cfg-2 at 128x128.  The bounds are
-    about 1.5x the measured values (printed): bf16 forward 6.1e-3 / gradient median 3.5e-2, fp16 forward 7.4e-4."""
+    about 1.5x the measured values (printed): bf16 forward 6.9e-3 / gradient median 2.4e-2 (3.5e-2 before the register-weight and fused-backward
+    kernels), fp16 forward 7.3e-4 / gradient median 1.0e-2 (7.8e-3 with DD_CONV_RW=0).  The per-tensor error grows from 5e-4 (compose net) and
+    3e-3 (decoder top) to 5e-2 at the 32x32 bottleneck (tools/grad_errors.py); which kernel family computes a layer moves the median by +-30 %
+    through the fp32 summation order alone -- single-layer errors are identical to 4 digits (tools/conv_case_errors.py)."""
     _need_gpu()
     aj, tj, B, H, W = configs.cfg2_unet_kpcn(), configs.bench_training(), 1, 128, 128
     oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, dtype, B, H, W, tj)
