@@ -163,6 +163,14 @@ template <> __device__ __forceinline__ uint4 pack8t<f16_t>(const float (&v)[8]) 
   return u;
 }
 // keep the bf16 / fp16 lanes of `v` whose mask lane is > 0 (sign bit clear and not zero: the same test in both formats) (ReLU-backward on packed data, no unpacking)
+// the same mask in compare-and-select form (the first version).  Kept for csrc/dd_conv_rw.hip, whose masks arrive by global loads: there the
+// packed form above measured 12-29 % SLOWER per launch (96->96 data gradient 104 -> 116 us, 96->192 213 -> 275 us), while it is the faster one
+// where the mask is read from LDS (csrc/dd_conv_bwd.hip: -18 us per launch)
+__device__ __forceinline__ uint32_t mask_bf16x2_cmp(uint32_t v, uint32_t m) {
+  const uint32_t lo = ((m & 0x8000u) == 0u && (m & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+  const uint32_t hi = ((m & 0x80000000u) == 0u && (m & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+  return v & (lo | hi);
+}
 __device__ __forceinline__ uint32_t mask_bf16x2(uint32_t v, uint32_t m) {
   // m > 0 as a float <=> m > 0 as a 16-bit integer (sign clear, not zero).  0 - m (saturating: -(-32768) must not wrap) is negative exactly
   // then; its arithmetic shift by 15 is the 0xffff / 0 keep mask of the half: three packed instructions per word

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
         uint2 o2;
         o2.x = pack2<T>(v[0], v[1]);
         o2.y = pack2<T>(v[2], v[3]);
-        if (MASK) { o2.x = mask_bf16x2(o2.x, mv[y % 4].x); o2.y = mask_bf16x2(o2.y, mv[y % 4].y); }
+        if (MASK) { o2.x = mask_bf16x2_cmp(o2.x, mv[y % 4].x); o2.y = mask_bf16x2_cmp(o2.y, mv[y % 4].y); }      // (not the packed form: dd_common.h)
         if (ACCUM) {
           float f8[8], g8[8];
           unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
