@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 #ifdef CBW_EXP_NO_DROLE
     const bool active = false;
 #else
-    const bool active = cb * 64 + wr * 16 < a.cin;
+    const bool active = a.dx != nullptr && cb * 64 + wr * 16 < a.cin;      // dx == NULL (the layer's input needs no gradient): these waves only feed the DMA
 #endif
     uint4 wf[9][2];
     {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
           const int k0 = kc * 32 + q * 8;
-          const bool ok = ci_row < a.n_pad && k0 < a.k_pad;
+          const bool ok = active && ci_row < a.n_pad && k0 < a.k_pad;
           wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + k0 : zw);
         }
     }
@@ -404,15 +404,15 @@ int launch_bwd(const BwdP& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
-  DD_REQUIRE(a && a->dy && a->x && a->wd && a->dx && a->dw, "dd_conv3x3_bwd: null pointer");
+  DD_REQUIRE(a && a->dy && a->x && a->dw && (a->wd || !a->dx), "dd_conv3x3_bwd: null pointer");      // dx (and then wd) may be NULL: weight / bias gradients only
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_bwd: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm + dd_conv_wgrad)", a->dtype);
   DD_REQUIRE(a->cout > 0 && a->cout <= 64 && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d (cout <= 64)", a->cout, a->cin);
   const int coutv = (a->cout + 7) / 8 * 8, cinv = (a->cin + 7) / 8 * 8;
-  DD_REQUIRE(a->ld_dy % 8 == 0 && a->ld_x % 8 == 0 && a->ld_dx % 4 == 0 && coutv <= a->ld_dy && cinv <= a->ld_x && cinv <= a->ld_dx,
+  DD_REQUIRE(a->ld_dy % 8 == 0 && a->ld_x % 8 == 0 && coutv <= a->ld_dy && cinv <= a->ld_x && (!a->dx || (a->ld_dx % 4 == 0 && cinv <= a->ld_dx)),
              "dd_conv3x3_bwd: ld_dy=%d ld_x=%d ld_dx=%d must cover the channel counts rounded to 8 (ld_dy, ld_x multiples of 8)", a->ld_dy, a->ld_x, a->ld_dx);
   DD_REQUIRE(((uintptr_t)a->dy % 16) == 0 && ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wd % 16) == 0 && ((uintptr_t)a->dx % 8) == 0,
              "dd_conv3x3_bwd: dy / x / wd must be 16-byte aligned, dx 8-byte aligned");
-  DD_REQUIRE(a->n_pad >= a->cin && a->k_pad >= a->cout && a->k_pad % 8 == 0, "dd_conv3x3_bwd: packed weights [9][n_pad=%d][k_pad=%d] do not cover %d x %d", a->n_pad, a->k_pad, a->cin, a->cout);
+  DD_REQUIRE(!a->dx || (a->n_pad >= a->cin && a->k_pad >= a->cout && a->k_pad % 8 == 0), "dd_conv3x3_bwd: packed weights [9][n_pad=%d][k_pad=%d] do not cover %d x %d", a->n_pad, a->k_pad, a->cin, a->cout);
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && (long)a->B * a->H * a->W < (1L << 31) / 256, "dd_conv3x3_bwd: empty or oversized grid");
   BwdP p;
   p.dy = a->dy; p.x = a->x; p.wd = a->wd; p.dx = a->dx; p.dw = a->dw; p.db = a->db;

@@ -311,19 +311,19 @@ class Graph:
     def _conv_bwd_call(self, gy, x, layer, wd, n_pad, k_pad, gx, use_mask, accumulate):
         """Data + weight + bias gradients of a 3x3 layer in one launch (csrc/dd_conv_bwd.hip)."""
         B, H, W = x.B, x.H, x.W
-        self.bwd_records.append({"flops": 4.0 * B * H * W * 9 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 9, "n": layer.cin, "k": layer.cout,
-                                 "accumulate": bool(accumulate)})
+        self.bwd_records.append({"flops": (4.0 if gx is not None else 2.0) * B * H * W * 9 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 9,
+                                 "n": layer.cin, "k": layer.cout, "accumulate": bool(accumulate), "weights_only": gx is None})
         ps = self.params
         a = L.ConvBwdArgs()
         a.dy, a.ld_dy, a.cout = gy.ptr, gy.ld, layer.cout
         a.x, a.ld_x, a.cin = x.ptr, x.ld, layer.cin
-        a.wd, a.n_pad, a.k_pad = wd.data_ptr(), n_pad, k_pad
-        a.dx, a.ld_dx = gx.ptr, gx.ld
+        a.wd, a.n_pad, a.k_pad = (wd.data_ptr() if wd is not None else None), n_pad, k_pad
+        a.dx, a.ld_dx = (gx.ptr, gx.ld) if gx is not None else (None, 0)
         a.dw, a.db = ps.grad_ptr(layer.kernel), ps.grad_ptr(layer.bias)
         a.B, a.H, a.W = B, H, W
         a.use_mask, a.accumulate, a.dtype = int(bool(use_mask)), int(bool(accumulate)), self.code
         lib = self.lib
-        keep = (gy.buf, x.buf, wd, gx.buf)
+        keep = (gy.buf, x.buf, wd, gx.buf if gx is not None else None)
 
         def run(stream, a=a, keep=keep):
             L.check(lib.dd_conv3x3_bwd(C.byref(a), stream))
@@ -399,14 +399,18 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             # one pass over dy and x for both gradients (3x3, <= 64 output channels, bf16 / f16 storage): csrc/dd_conv_bwd.hip
-            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout <= 64 and not in_relu and x.requires_grad
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout <= 64 and not in_relu and (x.requires_grad or layer.cin >= 16)
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):
-                wd, _, dn_pad, dk_pad = layer.packed("dgrad")
-                gx = x.grad()
-                use_mask, accumulate = x.relu, x.grad_written
-                self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, wd, dn_pad, dk_pad, gx, use_mask, accumulate), "conv_bwd"),
-                         grad_params=[layer.kernel, layer.bias])
-                x.mark_grad_written()
+                if x.requires_grad:
+                    wd, _, dn_pad, dk_pad = layer.packed("dgrad")
+                    gx = x.grad()
+                    use_mask, accumulate = x.relu, x.grad_written
+                    self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, wd, dn_pad, dk_pad, gx, use_mask, accumulate), "conv_bwd"),
+                             grad_params=[layer.kernel, layer.bias])
+                    x.mark_grad_written()
+                else:       # the network's first layer: weight / bias gradients only (the same launch, its data-gradient waves only feed the DMA)
+                    self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, None, 0, 0, None, False, False), "conv_bwd"),
+                             grad_params=[layer.kernel, layer.bias])
                 if res is not None and res.requires_grad:
                     self._masked_add_bwd(res, gy)
                 return

@@ -90,6 +90,13 @@ def test_conv_fused_backward(eng, dtype, cin, cout, H, W, x_relu, B):
     _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, x_relu, B=B, expect_fused_bwd=True)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W", [(32, 64, 32, 32), (24, 40, 20, 28), (72, 16, 16, 16)])
+def test_conv_first_layer_weight_gradients_only(eng, dtype, cin, cout, H, W):
+    """The network's first layer: its input needs no gradient -- the fused backward launch with dx = NULL computes dW / db only."""
+    _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, False, B=2, expect_fused_bwd=True, x_requires_grad=False)
+
+
 @pytest.mark.parametrize("k,cin,cout,H,W,B", [(1, 16, 27, 16, 32, 8), (1, 27, 27, 16, 32, 8), (3, 32, 16, 16, 32, 8), (1, 24, 1, 16, 32, 24),
                                                (3, 24, 24, 16, 32, 24), (1, 16, 27, 8, 16, 8), (3, 16, 16, 32, 16, 5), (3, 16, 16, 48, 16, 3)])
 def test_conv_non_square_batches(eng, k, cin, cout, H, W, B):
@@ -104,10 +111,10 @@ def test_conv_over_skip_concat_runs_as_two_resident_launches(eng, dtype, cin, co
     _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, split_at=split_at)
 
 
-def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None, expect_fused_bwd=False):
+def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None, expect_fused_bwd=False, x_requires_grad=True):
     gen = _gen(k * 1000 + cin + cout)
     g = eng.Graph("cuda", dtype)
-    x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=True)
+    x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=x_requires_grad)
     xv = torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64)
     if x_relu:
         xv = torch.relu(xv)
@@ -156,7 +163,8 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
     gx_want = grads[0] * (xv > 0) if (x_relu or in_relu) else grads[0]
-    check("dx", read(x.grad()), gx_want, tol * 2)
+    if x_requires_grad:
+        check("dx", read(x.grad()), gx_want, tol * 2)
     check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
     check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
     if residual:
