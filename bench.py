@@ -310,7 +310,8 @@ def main():
         esz = 4 if args.dtype == "f32" else 2
         alg_bytes = sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r["extra_reads"])) * esz for r in trainer.program.g.conv_records)
         tr = measured_traffic(B, args.dtype)
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (fwd+dgrad implicit GEMM)" % args.dtype, "achieved": achieved, "peak": peak,
+        roof = {"bound": "mfma", "kernel": "dd_conv_igemm launches <%s>: conv_igemm_ws_kernel, conv_rw_kernel, conv_rw8_kernel (forward + the data gradients the fused "
+                          "conv_bwd_kernel does not cover)" % args.dtype, "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": tr["bytes_per_launch"] if tr else None,
                 "traffic_source": tr["source"] if tr else None, "algorithmic_bytes_per_launch": alg_bytes / n,
                 "launches_per_step": n, "avg_launch_us": 1e3 * ms / n,
