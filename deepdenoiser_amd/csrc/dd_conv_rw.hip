@@ -20,7 +20,7 @@ struct RwP {
   int ldx, ldmask, ldy;
   int cin, cinv, n, n_pad, k_pad, nbias;
   int B, H, W, tiles_x, tiles_y, nblk, ksplit;
-  int relu, accum;
+  int relu, accum, aux_residual;      // aux_residual: `mask` / ldmask hold the residual operand
 };
 
 typedef uint32_t rw_u32x4 __attribute__((ext_vector_type(4)));
@@ -38,8 +38,11 @@ __device__ __forceinline__ uint4 rw_lds16(unsigned off) {
 
 struct RwTile { int b, y0, x0; bool live; };
 
-template <typename T, int KC, bool MASK, bool ACCUM>
+// AUX: the optional output-shaped operand read next to the results: 0 none, 1 ReLU-backward mask (y *= aux > 0), 2 residual (y = act(conv + aux),
+// the second half of a conv over a channel concat: engine.Graph.conv split_at)
+template <typename T, int KC, int AUX, bool ACCUM>
 __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
+  constexpr bool MASK = AUX != 0;      // (the loads of the aux rows are the same for both kinds)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   static_assert(sizeof(T) == 2, "register-weight conv: bf16 / fp16 storage");
   constexpr int PW = RW_PW, PH = RW_PH;
@@ -141,11 +144,19 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
       };
       auto write_row = [&](int y) {      // ReLU / mask / accumulate, round, store output row y
         f32x4_t v = acc[y % 4];
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.relu && AUX != 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         uint2 o2;
         o2.x = pack2<T>(v[0], v[1]);
         o2.y = pack2<T>(v[2], v[3]);
-        if (MASK) { o2.x = mask_bf16x2_cmp(o2.x, mv[y % 4].x); o2.y = mask_bf16x2_cmp(o2.y, mv[y % 4].y); }      // (not the packed form: dd_common.h)
+        if (AUX == 1) { o2.x = mask_bf16x2_cmp(o2.x, mv[y % 4].x); o2.y = mask_bf16x2_cmp(o2.y, mv[y % 4].y); }      // (not the packed form: dd_common.h)
+        if (AUX == 2) {      // the conv result is rounded where the layer-wise path stores it, then the residual is added and the activation applied
+          float f8[8], g8[8];
+          unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
+          unpack8t<T>(uint4{mv[y % 4].x, mv[y % 4].y, 0u, 0u}, g8);
+          o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
+          o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+          if (a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
+        }
         if (ACCUM) {
           float f8[8], g8[8];
           unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
@@ -345,19 +356,20 @@ static int rw_cus() {
   return n;
 }
 
-template <typename T, int KC, bool MASK, bool ACCUM>
+template <typename T, int KC, int AUX, bool ACCUM>
 static void rw_launch(const RwP& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw_kernel<T, KC, MASK, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw_kernel<T, KC, AUX, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_rw_kernel<T, KC, MASK, ACCUM>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(512), 2 * (size_t)RW_BUF, stream, p);
+  hipLaunchKernelGGL((conv_rw_kernel<T, KC, AUX, ACCUM>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(512), 2 * (size_t)RW_BUF, stream, p);
 }
 template <typename T, int KC>
 static void rw_launch_flags(const RwP& p, hipStream_t stream) {
-  if (p.mask) { if (p.accum) rw_launch<T, KC, true, true>(p, stream); else rw_launch<T, KC, true, false>(p, stream); }
-  else { if (p.accum) rw_launch<T, KC, false, true>(p, stream); else rw_launch<T, KC, false, false>(p, stream); }
+  if (p.aux_residual) rw_launch<T, KC, 2, false>(p, stream);
+  else if (p.mask) { if (p.accum) rw_launch<T, KC, 1, true>(p, stream); else rw_launch<T, KC, 1, false>(p, stream); }
+  else { if (p.accum) rw_launch<T, KC, 0, true>(p, stream); else rw_launch<T, KC, 0, false>(p, stream); }
 }
 
 }  // namespace
@@ -370,7 +382,9 @@ bool dd_conv_rw_eligible(const dd_conv_args* a) {
   if (on8 < 0) { const char* e = getenv("DD_CONV_RW8"); on8 = e ? atoi(e) : 1; }
   if (!on) return false;
   const int plain = DD_OUT_RELU | DD_ACCUM;
-  const bool common = a->taps == 9 && (a->dtype == DD_BF16 || a->dtype == DD_F16) && (a->flags & ~plain) == 0 && !a->res && a->k_pad % 32 == 0 &&
+  // a residual operand: only the 65..96-channel kernel, with nothing else in the epilogue (the second half of a conv over a channel concat)
+  const bool res_ok = !a->res || (!a->mask && !(a->flags & DD_ACCUM) && a->cin > 64 && a->cin <= 96 && a->ldres % 4 == 0 && ((uintptr_t)a->res % 8) == 0);
+  const bool common = a->taps == 9 && (a->dtype == DD_BF16 || a->dtype == DD_F16) && (a->flags & ~plain) == 0 && res_ok && a->k_pad % 32 == 0 &&
                       a->n % 4 == 0 && a->ldx % 8 == 0 && a->ldy % 4 == 0 && (!a->mask || a->ldmask % 4 == 0) && ((uintptr_t)a->x % 16) == 0 &&
                       ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0 && (!a->mask || ((uintptr_t)a->mask % 8) == 0);
   if (!common) return false;
@@ -392,8 +406,8 @@ static void rw8_launch(const RwP& p, hipStream_t stream) {
 
 int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
   RwP p;
-  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;
-  p.ldx = a->ldx; p.ldmask = a->ldmask; p.ldy = a->ldy;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->res ? a->res : a->mask; p.y = a->y;
+  p.ldx = a->ldx; p.ldmask = a->res ? a->ldres : a->ldmask; p.ldy = a->ldy; p.aux_residual = a->res != nullptr;
   p.cin = a->cin; p.cinv = (a->cin + 7) / 8 * 8; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad; p.nbias = a->nbias;
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
