@@ -32,7 +32,7 @@ struct BwdP {
   int cout, cin, coutv, cinv;      // logical / staged (rounded up to 8) channel counts
   int n_pad, k_pad;                // packed data-gradient weights [9][n_pad (ci)][k_pad (co)]
   int B, H, W, tiles_x, tiles_y;
-  int nblk, ksplit;                // 64-channel blocks of C_in; workgroups per block
+  int nblk, nblk_co, ksplit;       // 64-channel blocks of C_in / of C_out (> 1 only without a data gradient); workgroups per block pair
   int use_mask, accumulate;
 };
 
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
   static_assert(sizeof(T) == 2, "fused conv backward: bf16 / fp16 storage");
   constexpr int PW = BW_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = blockIdx.x / a.ksplit, ks = blockIdx.x - cb * a.ksplit;
+  const int pair = blockIdx.x / a.ksplit, ks = blockIdx.x - pair * a.ksplit;
+  const int ob = pair / a.nblk, cb = pair - ob * a.nblk;      // output- / input-channel block of this workgroup column
   const int wr = wave & 3;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int per_img = a.tiles_y * a.tiles_x;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
     const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const int r = lane >> 3, ls = (lane & 7) ^ r;
-    const int xch = cb * 64 + ls * 8, dch = ls * 8;
+    const int xch = cb * 64 + ls * 8, dch = ob * 64 + ls * 8;
     const bool x_ok = xch < a.cinv, d_ok = dch < a.coutv;
     const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
     const int x_row = a.W * a.ldx * 2, x_lane = (r * a.ldx + xch) * 2;                  // bytes
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 #ifdef CBW_EXP_NO_WROLE
     const bool active = false;
 #else
-    const bool active = wr * 16 < a.cout;
+    const bool active = ob * 64 + wr * 16 < a.cout;
 #endif
     const bool bias_wave = a.db != nullptr && cb == 0;
     const int nci = min(4, (a.cin - cb * 64 + 15) >> 4);        // input-channel tiles of this block that exist
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (see bw_mma_inplace)
     // flush: D[t][i] rows = input channels i*16 + q4 + e, column = output channel wr*16 + li; shifted-dy tap t is TensorFlow's tap 8 - t
     if (active) {
-      const int co = wr * 16 + li;
+      const int co = ob * 64 + wr * 16 + li;
       if (co < a.cout) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -390,7 +391,7 @@ int launch_bwd_flags(const BwdP& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<T, MASK, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const long blocks = (long)p.nblk * p.ksplit;
+  const long blocks = (long)p.nblk * p.nblk_co * p.ksplit;
   hipLaunchKernelGGL((conv_bwd_kernel<T, MASK, ACCUM>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -406,7 +407,7 @@ int launch_bwd(const BwdP& p, hipStream_t stream) {
 extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->dy && a->x && a->dw && (a->wd || !a->dx), "dd_conv3x3_bwd: null pointer");      // dx (and then wd) may be NULL: weight / bias gradients only
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_bwd: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm + dd_conv_wgrad)", a->dtype);
-  DD_REQUIRE(a->cout > 0 && a->cout <= 64 && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d (cout <= 64)", a->cout, a->cin);
+  DD_REQUIRE(a->cout > 0 && (a->cout <= 64 || !a->dx) && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d (cout <= 64 unless dx is NULL)", a->cout, a->cin);
   const int coutv = (a->cout + 7) / 8 * 8, cinv = (a->cin + 7) / 8 * 8;
   DD_REQUIRE(a->ld_dy % 8 == 0 && a->ld_x % 8 == 0 && coutv <= a->ld_dy && cinv <= a->ld_x && (!a->dx || (a->ld_dx % 4 == 0 && cinv <= a->ld_dx)),
              "dd_conv3x3_bwd: ld_dy=%d ld_x=%d ld_dx=%d must cover the channel counts rounded to 8 (ld_dy, ld_x multiples of 8)", a->ld_dy, a->ld_x, a->ld_dx);
@@ -421,9 +422,9 @@ extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   p.n_pad = a->n_pad; p.k_pad = a->k_pad;
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
-  p.nblk = dd_ceil_div(a->cin, 64);
+  p.nblk = dd_ceil_div(a->cin, 64); p.nblk_co = dd_ceil_div(a->cout, 64);
   const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
-  long ksplit = bwd_cus() / p.nblk;
+  long ksplit = bwd_cus() / (p.nblk * p.nblk_co);
   if (ksplit < 1) ksplit = 1;
   if (ksplit > total_tiles) ksplit = total_tiles;
   p.ksplit = (int)ksplit;

@@ -308,10 +308,13 @@ class Graph:
         run.info = self.wgrad_records[-1]
         return run
 
-    def _conv_bwd_call(self, gy, x, layer, wd, n_pad, k_pad, gx, use_mask, accumulate):
-        """Data + weight + bias gradients of a 3x3 layer in one launch (csrc/dd_conv_bwd.hip)."""
+    def _conv_bwd_call(self, gy, x, layer, wd, n_pad, k_pad, gx, use_mask, accumulate, as_wgrad=False):
+        """Data + weight + bias gradients of a 3x3 layer in one launch (csrc/dd_conv_bwd.hip); gx None: weight / bias gradients only
+        (as_wgrad: accounted with the weight-gradient launches)."""
         B, H, W = x.B, x.H, x.W
-        self.bwd_records.append({"flops": (4.0 if gx is not None else 2.0) * B * H * W * 9 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 9,
+        if as_wgrad:
+            self.wgrad_records.append({"flops": 2.0 * B * H * W * 9 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 9, "m": layer.cin, "n": layer.cout})
+        (self.bwd_records if not as_wgrad else []).append({"flops": (4.0 if gx is not None else 2.0) * B * H * W * 9 * layer.cin * layer.cout, "B": B, "H": H, "W": W, "taps": 9,
                                  "n": layer.cin, "k": layer.cout, "accumulate": bool(accumulate), "weights_only": gx is None})
         ps = self.params
         a = L.ConvBwdArgs()
@@ -327,7 +330,7 @@ class Graph:
 
         def run(stream, a=a, keep=keep):
             L.check(lib.dd_conv3x3_bwd(C.byref(a), stream))
-        run.info = self.bwd_records[-1]
+        run.info = self.wgrad_records[-1] if as_wgrad else self.bwd_records[-1]
         return run
 
     def _convt_call(self, x, y, layer, w, n_pad, k_pad, relu, gx=None, use_mask=False, accumulate=False):
@@ -415,8 +418,14 @@ class Graph:
                     self._masked_add_bwd(res, gy)
                 return
             wflags = L.IN_RELU if in_relu else 0
-            self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags,
-                                                          ps.grad_ptr(layer.bias), 1), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 96 and not in_relu and layer.cin >= 16
+                    and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0" and os.environ.get("DD_WGRAD_VIA_BWD", "1") != "0"):
+                # > 96 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair (dx = NULL)
+                self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, None, 0, 0, None, False, False, as_wgrad=True), "conv_wgrad"),
+                         grad_params=[layer.kernel, layer.bias])
+            else:
+                self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags,
+                                                              ps.grad_ptr(layer.bias), 1), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])
             if x.requires_grad:
                 wd, dtaps, dn_pad, dk_pad = layer.packed("dgrad")
                 gx = x.grad()

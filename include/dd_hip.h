@@ -103,7 +103,7 @@ typedef struct {
   const void* dy; int ld_dy; int cout; /* gradient of the layer's output [B,H,W,ld_dy]; channels up to the next multiple of 8 readable and zero */
   const void* x; int ld_x; int cin;    /* the layer's input [B,H,W,ld_x] (weight-gradient operand and ReLU mask of dx) */
   const void* wd; int n_pad; int k_pad;/* data-gradient weights as dd_pack_weights lays them out for dd_conv_igemm: [9][n_pad (ci)][k_pad (co)] */
-  void* dx; int ld_dx;                 /* [B,H,W,ld_dx]; NULL (then wd may be NULL too): the layer's input needs no gradient, only dw / db are computed */
+  void* dx; int ld_dx;                 /* [B,H,W,ld_dx]; NULL (then wd may be NULL too, and cout may exceed 64): only dw / db are computed */
   float* dw; float* db;                /* db may be NULL */
   int B, H, W;
   int use_mask; int accumulate; int dtype;
