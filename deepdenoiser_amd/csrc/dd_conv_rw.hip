@@ -212,13 +212,16 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
 // 16 x 8 tiles (18 x 10 haloed: 2 x 23 chunks) -- either way <= 46 KiB per buffer
 template <int KC> struct RfGeo {
   static constexpr int NS = (KC + 1) / 2, TH = NS == 1 ? DD_TILE : DD_TILE / 2, PW = DD_TILE + 2, PH = TH + 2;
-  static constexpr int CH = (PW * PH + 7) / 8, SLICE = CH * 1024, BUF = NS * SLICE, NCHUNK = NS * CH, NPIECE = (NCHUNK + 7) / 8;
+  static constexpr int CH = (PW * PH + 7) / 8, SLICE = CH * 1024, BUF = NS * SLICE, NCHUNK = NS * CH;
 };
 
-template <typename T, int KC>
-__global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
+// NW = waves per workgroup: 8 (blocks of 4 output-channel tiles = 64 channels) or 12 (3 per SIMD, <= 168 registers: blocks of 6 tiles = 96
+// channels -- the balanced form of the 96-channel forward, whose 6 + 2 wave kernel above loads two SIMDs with two compute waves and two with one)
+template <typename T, int KC, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using G = RfGeo<KC>;
+  constexpr int CT = NW / 2, NPIECE = (G::NCHUNK + NW - 1) / NW;      // output-channel tiles per block; DMA pieces per wave and tile
   constexpr int PW = G::PW, RH = G::TH / 2, PHW = RH + 2;      // a wave's RH output rows need RH + 2 haloed rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
   const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
   const char* X = reinterpret_cast<const char*>(a.x);
   auto piece = [&](int k, const RwTile& t, unsigned buf) {
-    const int id = k * 8 + wave;
+    const int id = k * NW + wave;
     if (id < G::NCHUNK) {      // wave-uniform
       int rr = r;
       asm volatile("" : "+v"(rr));      // (keeps the per-piece coordinates from being hoisted out of the tile loop: see csrc/dd_conv_bwd.hip)
@@ -255,11 +258,11 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
   };
   RwTile cur = tile_at(tile0);
 #pragma unroll
-  for (int k = 0; k < G::NPIECE; ++k) piece(k, cur, lds_base);
+  for (int k = 0; k < NPIECE; ++k) piece(k, cur, lds_base);
 
   // ---- compute: output-channel tile (wave & 3) of block blk, output rows RH*(wave >> 2) .. + RH - 1
   const int li = lane & 15, q = lane >> 4;
-  const int cot = blk * 4 + (wave & 3), half = wave >> 2;
+  const int cot = blk * CT + wave % CT, half = wave / CT;
   const bool active = cot * 16 < a.n;
   const int nrow = cot * 16 + li, c4 = cot * 16 + q * 4;
   uint4 wf[9][KC];
@@ -293,14 +296,14 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
     const unsigned nbuf = lds_base + (sel ^ 1) * G::BUF;
     if (!active) {
 #pragma unroll
-      for (int k = 0; k < G::NPIECE; ++k) piece(k, nxt, nbuf);
+      for (int k = 0; k < NPIECE; ++k) piece(k, nxt, nbuf);
       cur = nxt;
       continue;
     }
     const bool col_ok = ch_ok && cur.x0 + li < a.W;
     T* yp = Y + (((long)cur.b * a.H + cur.y0 + half * RH) * a.W + cur.x0 + li) * a.ldy + c4;
     f32x4_t acc[4];
-    constexpr int FR = 3 * KC, NF = PHW * FR, RING = 6, AHEAD = RING - 1;
+    constexpr int FR = 3 * KC, NF = PHW * FR, RING = NW == 8 ? 6 : 2, AHEAD = RING - 1;      // (12 waves: 168 registers, 108 of them weights)
     uint4 ring[RING];
     auto frag = [&](int f) {
       const int yy = f / FR, j = f - FR * yy, dx = j / KC, kc = j - KC * dx, C = yy * PW + dx;
@@ -325,8 +328,8 @@ __global__ __launch_bounds__(512) void conv_rw8_kernel(const RwP a) {
         if (j == 0 && yy < RH) acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
         if (j == 2 && yy >= 3) write_row(yy - 3);
         {      // the DMA pieces of the next tile, spread evenly over the NF steps
-          const int k0 = (f * G::NPIECE + NF - 1) / NF;
-          if (k0 < G::NPIECE && (k0 * NF) / G::NPIECE == f) piece(k0, nxt, nbuf);
+          const int k0 = (f * NPIECE + NF - 1) / NF;
+          if (k0 < NPIECE && (k0 * NF) / NPIECE == f) piece(k0, nxt, nbuf);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -394,14 +397,14 @@ bool dd_conv_rw_eligible(const dd_conv_args* a) {
          !(a->flags & DD_ACCUM) && a->n >= 48;
 }
 
-template <typename T, int KC>
+template <typename T, int KC, int NW = 8>
 static void rw8_launch(const RwP& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_rw8_kernel<T, KC>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(512), 2 * (size_t)RfGeo<KC>::BUF, stream, p);
+  hipLaunchKernelGGL((conv_rw8_kernel<T, KC, NW>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(NW * 64), 2 * (size_t)RfGeo<KC>::BUF, stream, p);
 }
 
 int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
@@ -411,16 +414,22 @@ int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
   p.cin = a->cin; p.cinv = (a->cin + 7) / 8 * 8; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad; p.nbias = a->nbias;
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
-  const bool six = a->cin > 64 && a->cin <= 96;      // 6 compute + 2 I/O waves, any epilogue; else all 8 waves, forward only
-  const int th = six ? RW_TH : (a->cin <= 64 ? RfGeo<2>::TH : RfGeo<4>::TH);
+  static int on12 = -1;
+  if (on12 < 0) { const char* e = getenv("DD_CONV_RW12"); on12 = e ? atoi(e) : 1; }
+  const bool plain_fwd = !a->mask && !a->res && !(a->flags & DD_ACCUM);
+  const bool twelve = on12 && a->cin > 64 && a->cin <= 96 && plain_fwd && a->n >= 48;      // all 12 waves compute (forward only)
+  const bool six = a->cin > 64 && a->cin <= 96 && !twelve;      // 6 compute + 2 I/O waves, any epilogue; else all waves compute, forward only
+  const int th = six ? RW_TH : (a->cin <= 64 ? RfGeo<2>::TH : RfGeo<4>::TH);      // (RfGeo<3>::TH == RfGeo<4>::TH == 8)
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, th);
-  p.nblk = dd_ceil_div(a->n, six ? 96 : 64);
+  p.nblk = dd_ceil_div(a->n, (six || twelve) ? 96 : 64);
   const long total = (long)a->B * p.tiles_x * p.tiles_y;
   long ksplit = rw_cus() / p.nblk;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > total) ksplit = total;
   p.ksplit = (int)ksplit;
-  if (six) {
+  if (twelve) {
+    if (a->dtype == DD_BF16) rw8_launch<bf16_t, 3, 12>(p, stream); else rw8_launch<f16_t, 3, 12>(p, stream);
+  } else if (six) {
     if (a->dtype == DD_BF16) rw_launch_flags<bf16_t, 3>(p, stream); else rw_launch_flags<f16_t, 3>(p, stream);
   } else if (a->cin <= 64) {
     if (a->dtype == DD_BF16) rw8_launch<bf16_t, 2>(p, stream); else rw8_launch<f16_t, 2>(p, stream);
