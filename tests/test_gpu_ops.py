@@ -422,3 +422,21 @@ def test_conv_random_shapes(eng, seed):
     B = rng.choice([1, 2, 3])
     for dtype in ("f32", "bf16", "f16"):
         _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B=B)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_conv3x3_random_shapes_round2_kernels(eng, seed):
+    """Seeded sweep aimed at the round-2 kernels' shape ranges (bf16 / f16): register-weight forward on 8 / 12 waves and the 6 + 2 wave kernel
+    (csrc/dd_conv_rw.hip: <= 64, 65..96, 97..128 channels of depth; mask / accumulate / residual epilogues), the fused backward with and
+    without a data gradient (csrc/dd_conv_bwd.hip), the single-pass 96-channel weight gradient (csrc/dd_conv_wgrad96.hip); images of several
+    16x16 / 16x8 tiles with ragged edges so that the tile walks, halos and zero padding are exercised."""
+    import random
+    rng = random.Random(7000 + seed)
+    cin = rng.choice([24, 32, 48, 64, 72, 80, 96, 104, 128, 160, 192])
+    cout = rng.choice([16, 48, 64, 80, 96, 128])
+    H, W = rng.choice([9, 16, 23, 40, 57]), rng.choice([8, 17, 32, 45, 70])
+    relu, residual = rng.random() < 0.7, rng.random() < 0.25
+    x_relu = rng.random() < 0.7
+    B = rng.choice([1, 2, 3])
+    for dtype in ("bf16", "f16"):
+        _conv_case(eng, dtype, 3, cin, cout, H, W, relu, False, residual, x_relu, B=B, x_requires_grad=rng.random() < 0.85)
