@@ -25,6 +25,7 @@ struct CtP {
   int n_pad, k_pad;                // packed weights: fwd [4*cout -> n_pad][k_pad (ci)], bwd [4][n_pad (ci)][k_pad (co)]
   int B, H, W, tiles_x, tiles_y, nwg;
   int relu;
+  int co_off, cout_total;          // backward over a block of output channels [co_off, co_off + cout) of cout_total (dy / weight / dK / db offsets)
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* ct_tr_ptr;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void ct_dma_y(const CtP& a, const CtTile& t, int c, u
   const int row = cc >> 1, col = (cc & 1) * 8 + r, ch = sd * 64 + ls * 8;
   const int gy = 2 * t.i0 + row, gx = 2 * t.j0 + col;
   const bool ok = t.live && ch < a.coutv && gy < 2 * a.H && gx < 2 * a.W;
-  const char* src = reinterpret_cast<const char*>(a.y) + (((long)t.b * 2 * a.H + gy) * 2 * a.W + gx) * a.ldy * 2 + ch * 2;
+  const char* src = reinterpret_cast<const char*>(a.y) + (((long)t.b * 2 * a.H + gy) * 2 * a.W + gx) * a.ldy * 2 + (a.co_off + ch) * 2;
   ct_dma_1k(ok ? src : reinterpret_cast<const char*>(&dd_zero16_v), lds + c * 1024);
 }
 
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
         const int k0 = kc * 32 + q * 8;
-        const bool ok = ci_row < a.n_pad && k0 < a.k_pad;
-        wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + k0 : zw);
+        const bool ok = ci_row < a.n_pad && k0 < a.coutv && a.co_off + k0 < a.k_pad;
+        wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + a.co_off + k0 : zw);
       }
   }
   // dy image addresses: input pixel (2g + (li >> 3), li & 7) of group g, tap (ta, tb) -> dy pixel pd = (2*row + ta) * 16 + 2*col + tb;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = (h * JW + j) * 16 + q * 4 + e;
-          if (co < a.cout) atomicAdd(a.dw + ((long)tw * a.cout + co) * a.cin + ci, wacc[j][i][e]);
+          if (co < a.cout) atomicAdd(a.dw + ((long)tw * a.cout_total + a.co_off + co) * a.cin + ci, wacc[j][i][e]);
         }
       }
     if (a.db) {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
         b += __shfl_xor(b, 16);
         b += __shfl_xor(b, 32);
         const int co = (h * JW + j) * 16 + li;
-        if (lane < 16 && co < a.cout) atomicAdd(a.db + co, b);
+        if (lane < 16 && co < a.cout) atomicAdd(a.db + a.co_off + co, b);
       }
     }
   }
@@ -380,11 +381,11 @@ static void ct_launch(K kernel, const CtP& p, size_t lds, hipStream_t stream) {
 }
 
 static int ct_fill(CtP& p, const dd_convt_args* a, bool bwd) {
-  const int th = (bwd && a && a->cout > 64) ? CT_T / 2 : CT_T;      // backward with two dy slices: tiles of 8 x 4
+  const int th = CT_T;
   DD_REQUIRE(a && a->x && a->y && a->w, "dd_convt2x2: null pointer");
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_convt2x2: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm / dd_conv_wgrad)", a->dtype);
-  DD_REQUIRE(a->cin > 0 && a->cin <= 128 && a->cout > 0 && a->cout <= (bwd ? 64 : 96) && a->cout % 16 == 0,
-             "dd_convt2x2: cin=%d cout=%d (cin <= 128; cout a multiple of 16, <= 96 forward / 64 backward)", a->cin, a->cout);
+  DD_REQUIRE(a->cin > 0 && a->cin <= 128 && a->cout > 0 && a->cout <= (bwd ? 128 : 96) && a->cout % 16 == 0,
+             "dd_convt2x2: cin=%d cout=%d (cin <= 128; cout a multiple of 16, <= 96 forward / 128 backward)", a->cin, a->cout);
   const int cinv = (a->cin + 7) / 8 * 8, coutv = (a->cout + 7) / 8 * 8;
   DD_REQUIRE(a->ld_x % 8 == 0 && a->ld_y % 8 == 0 && cinv <= a->ld_x && coutv <= a->ld_y, "dd_convt2x2: ld_x=%d ld_y=%d must be multiples of 8 covering the channels", a->ld_x, a->ld_y);
   DD_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->y % 16) == 0 && ((uintptr_t)a->w % 16) == 0, "dd_convt2x2: x / y / w must be 16-byte aligned");
@@ -396,6 +397,7 @@ static int ct_fill(CtP& p, const dd_convt_args* a, bool bwd) {
   const long total = (long)a->B * p.tiles_x * p.tiles_y;
   p.nwg = (int)(total < ct_cus() ? total : ct_cus());
   p.relu = a->relu;
+  p.co_off = 0; p.cout_total = a->cout;
   return DD_OK;
 }
 
@@ -431,15 +433,19 @@ extern "C" int dd_convt2x2_bwd(const dd_convt_args* a, dd_stream stream) {
   DD_REQUIRE(a->ld_dx % 4 == 0 && cinv <= a->ld_dx && ((uintptr_t)a->dx % 8) == 0, "dd_convt2x2_bwd: ld_dx=%d / dx alignment", a->ld_dx);
   p.out = a->dx; p.ldo = a->ld_dx; p.dw = a->dw; p.db = a->db; p.bias = nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t lds = 2 * (size_t)CT_BWD_BUF;      // (two dy slices: 2 x 40 KiB are used)
-#define CT_BWD_N(T, N)                                                                                     \
-  if (a->use_mask) { if (a->accumulate) ct_launch(convt_bwd_kernel<T, N, true, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, N, true, false>, p, lds, s); } \
-  else { if (a->accumulate) ct_launch(convt_bwd_kernel<T, N, false, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, N, false, false>, p, lds, s); }
-  // (NSD = 2 -- two dy slices, C_out <= 128 -- compiles but spills 11 registers next to the in-place asm MFMAs, whose results the compiler may then
-  //  store before they are written: measured wrong in f16.  Only the spill-free NSD = 1 is instantiated; wider layers take the layer-wise path.)
-#define CT_BWD(T) CT_BWD_N(T, 1)
-  if (a->dtype == DD_BF16) { CT_BWD(bf16_t) } else { CT_BWD(f16_t) }
-#undef CT_BWD
+  const size_t lds = 2 * (size_t)CT_BWD_BUF;
+#define CT_BWD_N(T, N, ACC)                                                                                \
+  if (a->use_mask) { if (ACC) ct_launch(convt_bwd_kernel<T, N, true, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, N, true, false>, p, lds, s); } \
+  else { if (ACC) ct_launch(convt_bwd_kernel<T, N, false, true>, p, lds, s); else ct_launch(convt_bwd_kernel<T, N, false, false>, p, lds, s); }
+  // More than 64 output channels: one launch per block of 64 (dy is one 64-channel LDS slice per launch), the later ones accumulating into dx.
+  // (A two-slice instantiation -- NSD = 2 -- compiles but spills 11 registers next to the in-place asm MFMAs, whose results the compiler may
+  //  then store before they are written: measured wrong in f16, so it is not instantiated.)
+  for (int co_off = 0; co_off < a->cout; co_off += 64) {
+    const int cb = a->cout - co_off < 64 ? a->cout - co_off : 64;
+    p.co_off = co_off; p.cout = cb; p.coutv = (cb + 7) / 8 * 8; p.cout_total = a->cout;
+    const bool acc = a->accumulate || co_off > 0;
+    if (a->dtype == DD_BF16) { CT_BWD_N(bf16_t, 1, acc) } else { CT_BWD_N(f16_t, 1, acc) }
+  }
 #undef CT_BWD_N
   DD_LAUNCH_CHECK();
   return DD_OK;

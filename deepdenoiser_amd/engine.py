@@ -482,7 +482,7 @@ class Graph:
             if not y.grad_written:
                 return
             gy = y.grad()
-            if stream_ok and layer.cout <= 64 and x.requires_grad:
+            if stream_ok and layer.cout <= 128 and x.requires_grad:
                 wd, _, dn_pad, dk_pad = layer.packed("dgrad")
                 gx = x.grad()
                 use_mask, accumulate = x.relu, x.grad_written

@@ -112,7 +112,7 @@ int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream);
 
 /* ---- 2x2 / stride-2 transposed convolution (tf.layers.conv2d_transpose(filters, 2, strides=2), UNet.py:54-59) as streaming kernels: the
  * forward (+ bias, ReLU), and the data + weight + bias gradients of TensorFlow's autodiff (Training.py:701-702) in ONE launch.  bf16 / f16
- * storage, cin <= 128, cout a multiple of 16 (<= 96 forward, <= 64 backward).  x [B,H,W,ld_x], y / dy [B,2H,2W,ld_y];
+ * storage, cin <= 128, cout a multiple of 16 (<= 96 forward, <= 128 backward: blocks of 64 run as consecutive launches).  x [B,H,W,ld_x], y / dy [B,2H,2W,ld_y];
  * kernel K[a][b][co][ci] (TensorFlow layout [2][2][cout][cin]):
  *   forward : y[2i+a][2j+b][co] = act(bias[co] + sum_ci x[i][j][ci] K[a][b][co][ci]);  w = dd_pack_weights layout [4*cout -> n_pad][k_pad (ci)]
  *   backward: dx[i][j][ci] = (use_mask ? x > 0 : 1) * sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci]   (accumulate: added to dx);
