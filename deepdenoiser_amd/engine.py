@@ -418,7 +418,7 @@ class Graph:
                     self._masked_add_bwd(res, gy)
                 return
             wflags = L.IN_RELU if in_relu else 0
-            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 96 and not in_relu and layer.cin >= 16
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and (layer.cout > 96 or (layer.cout > 64 and layer.cin <= 64)) and not in_relu and layer.cin >= 16
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0" and os.environ.get("DD_WGRAD_VIA_BWD", "1") != "0"):
                 # > 96 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair (dx = NULL)
                 self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, None, 0, 0, None, False, False, as_wgrad=True), "conv_wgrad"),
