@@ -418,9 +418,11 @@ class Graph:
                     self._masked_add_bwd(res, gy)
                 return
             wflags = L.IN_RELU if in_relu else 0
-            if (layer.k == 3 and self.dtype in ("bf16", "f16") and (layer.cout > 96 or (layer.cout > 64 and layer.cin <= 64)) and not in_relu and layer.cin >= 16
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 64 and not in_relu and layer.cin >= 16
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0" and os.environ.get("DD_WGRAD_VIA_BWD", "1") != "0"):
-                # > 96 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair (dx = NULL)
+                # > 64 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair of 64 x 64
+                # channels (dx = NULL).  Measured faster than both dedicated weight-gradient kernels: 96->96 at 64x64 154 -> 115 us against
+                # csrc/dd_conv_wgrad96.hip, 128->128 at 32x32 71 -> 60 us against csrc/dd_conv_wgrad.hip
                 self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, None, 0, 0, None, False, False, as_wgrad=True), "conv_wgrad"),
                          grad_params=[layer.kernel, layer.bias])
             else:
