@@ -33,6 +33,7 @@ struct BwdP {
   int n_pad, k_pad;                // packed data-gradient weights [9][n_pad (ci)][k_pad (co)]
   int B, H, W, tiles_x, tiles_y;
   int nblk, nblk_co, ksplit;       // 64-channel blocks of C_in / of C_out (> 1 only without a data gradient); workgroups per block pair
+  int co_base;                     // with a data gradient and C_out > 64: this LAUNCH covers output channels [co_base, co_base + 64) (host loop)
   int use_mask, accumulate;
 };
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
   constexpr int PW = BW_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = blockIdx.x / a.ksplit, ks = blockIdx.x - pair * a.ksplit;
-  const int ob = pair / a.nblk, cb = pair - ob * a.nblk;      // output- / input-channel block of this workgroup column
+  const int cb = pair % a.nblk, ob = pair / a.nblk + (a.co_base >> 6);      // input- / output-channel block of this workgroup column
   const int wr = wave & 3;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int per_img = a.tiles_y * a.tiles_x;
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
           const int k0 = kc * 32 + q * 8;
-          const bool ok = active && ci_row < a.n_pad && k0 < a.k_pad;
-          wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + k0 : zw);
+          const bool ok = active && ci_row < a.n_pad && ob * 64 + k0 < a.k_pad;
+          wf[t][kc] = *reinterpret_cast<const uint4*>(ok ? Wd + ((long)t * a.n_pad + ci_row) * a.k_pad + ob * 64 + k0 : zw);
         }
     }
     // Fragment addresses (32-bit LDS offsets of the CURRENT buffer; they flip by +-BW_BUF per tile).  dy image: pixel C + li (C = row*18 + dx,
@@ -407,7 +408,7 @@ int launch_bwd(const BwdP& p, hipStream_t stream) {
 extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->dy && a->x && a->dw && (a->wd || !a->dx), "dd_conv3x3_bwd: null pointer");      // dx (and then wd) may be NULL: weight / bias gradients only
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_bwd: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm + dd_conv_wgrad)", a->dtype);
-  DD_REQUIRE(a->cout > 0 && (a->cout <= 64 || !a->dx) && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d (cout <= 64 unless dx is NULL)", a->cout, a->cin);
+  DD_REQUIRE(a->cout > 0 && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d", a->cout, a->cin);
   const int coutv = (a->cout + 7) / 8 * 8, cinv = (a->cin + 7) / 8 * 8;
   DD_REQUIRE(a->ld_dy % 8 == 0 && a->ld_x % 8 == 0 && coutv <= a->ld_dy && cinv <= a->ld_x && (!a->dx || (a->ld_dx % 4 == 0 && cinv <= a->ld_dx)),
              "dd_conv3x3_bwd: ld_dy=%d ld_x=%d ld_dx=%d must cover the channel counts rounded to 8 (ld_dy, ld_x multiples of 8)", a->ld_dy, a->ld_x, a->ld_dx);
@@ -422,14 +423,24 @@ extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   p.n_pad = a->n_pad; p.k_pad = a->k_pad;
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
-  p.nblk = dd_ceil_div(a->cin, 64); p.nblk_co = dd_ceil_div(a->cout, 64);
+  p.nblk = dd_ceil_div(a->cin, 64);
   const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // Without a data gradient the output-channel blocks are workgroup columns of ONE launch.  With one, a launch covers 64 output channels (its
+  // data-gradient role sums over all of them): wider layers run as consecutive launches, the later ones accumulating into dx (the ReLU mask
+  // distributes over the partial sums; dx is rounded once more per extra launch, as with any accumulated gradient).
+  const int n_launch = a->dx ? dd_ceil_div(a->cout, 64) : 1;
+  p.nblk_co = a->dx ? 1 : dd_ceil_div(a->cout, 64);
   long ksplit = bwd_cus() / (p.nblk * p.nblk_co);
   if (ksplit < 1) ksplit = 1;
   if (ksplit > total_tiles) ksplit = total_tiles;
   p.ksplit = (int)ksplit;
-  p.use_mask = a->use_mask; p.accumulate = a->accumulate;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == DD_BF16) return launch_bwd<bf16_t>(p, s);
-  return launch_bwd<f16_t>(p, s);
+  p.use_mask = a->use_mask;
+  for (int l = 0; l < n_launch; ++l) {
+    p.co_base = l * 64;
+    p.accumulate = a->accumulate || l > 0;
+    const int rc = a->dtype == DD_BF16 ? launch_bwd<bf16_t>(p, s) : launch_bwd<f16_t>(p, s);
+    if (rc != DD_OK) return rc;
+  }
+  return DD_OK;
 }

@@ -402,7 +402,10 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             # one pass over dy and x for both gradients (3x3, <= 64 output channels, bf16 / f16 storage): csrc/dd_conv_bwd.hip
-            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout <= 64 and not in_relu and (x.requires_grad or layer.cin >= 16)
+            # (more than 64 output channels: dd_conv3x3_bwd runs one launch per 64 of them, each re-reading x and re-writing dx -- measured
+            #  slower than the register-weight data gradient + the weight-gradient role: 4.80 against 4.10 ms per step; opt-in only)
+            wide_ok = layer.cout <= 64 or (x.requires_grad and os.environ.get("DD_FUSE_CONV_BWD_WIDE", "0") != "0")
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and wide_ok and not in_relu and (x.requires_grad or layer.cin >= 16)
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):
                 if x.requires_grad:
                     wd, _, dn_pad, dk_pad = layer.packed("dgrad")
