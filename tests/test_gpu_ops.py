@@ -440,3 +440,12 @@ def test_conv3x3_random_shapes_round2_kernels(eng, seed):
     B = rng.choice([1, 2, 3])
     for dtype in ("bf16", "f16"):
         _conv_case(eng, dtype, 3, cin, cout, H, W, relu, False, residual, x_relu, B=B, x_requires_grad=rng.random() < 0.85)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W", [(96, 96, 20, 28), (128, 128, 16, 16), (64, 80, 9, 33)])
+def test_conv_fused_backward_wide_layers_opt_in(eng, dtype, cin, cout, H, W, monkeypatch):
+    """dd_conv3x3_bwd with more than 64 output channels AND a data gradient: one launch per 64 output channels, the later ones accumulating
+    into dx (opt-in, DD_FUSE_CONV_BWD_WIDE=1: measured slower than the split path, kept correct)."""
+    monkeypatch.setenv("DD_FUSE_CONV_BWD_WIDE", "1")
+    _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, expect_fused_bwd=True)
