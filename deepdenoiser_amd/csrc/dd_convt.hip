@@ -376,7 +376,16 @@ static int ct_cus() {
 
 template <typename K>
 static void ct_launch(K kernel, const CtP& p, size_t lds, hipStream_t stream) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // (the attribute is set once per kernel instantiation: a small set, looked up by function address)
+  static const void* done[32];
+  static int n_done = 0;
+  const void* f = reinterpret_cast<const void*>(kernel);
+  bool seen = false;
+  for (int i = 0; i < n_done; ++i) seen = seen || done[i] == f;
+  if (!seen) {
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (n_done < 32) done[n_done++] = f;
+  }
   hipLaunchKernelGGL(kernel, dim3((unsigned)p.nwg), dim3(512), lds, stream, p);
 }
 
