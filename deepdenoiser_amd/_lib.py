@@ -149,6 +149,27 @@ class RecombineDesc(C.Structure):
 _lib = None
 
 
+def _check_source_hash(lib):
+    """The .so travels prebuilt (git-ignored) next to its sources: refuse one that was built from different sources (dd_version() carries
+    the hash of csrc/* and include/dd_hip.h it was compiled from, deepdenoiser_amd/build.py).  DD_LIB experiment builds are exempt."""
+    if "DD_LIB" in os.environ:
+        return
+    from . import build as _build
+    try:
+        want = _build.source_hash()
+    except OSError:          # an installation without the sources next to the library: nothing to compare with
+        return
+    got = lib.dd_version().decode()
+    if ("src=" + want) not in got:
+        raise RuntimeError("libdd_hip.so is stale: built from sources %s, the sources here hash to %s -- run `python -m deepdenoiser_amd.build`"
+                           % (got.split("src=")[-1], want))
+
+
+def source_hash():
+    """Hash of the kernel sources the loaded library was built from (== build.source_hash() of the tree, checked at load time)."""
+    return load().dd_version().decode().split("src=")[-1]
+
+
 def load():
     """Returns the loaded library; raises RuntimeError (never falls back) if it is unavailable."""
     global _lib
@@ -166,6 +187,7 @@ def load():
         raise RuntimeError("libdd_hip.so lacks symbols %s: rebuild it" % missing)
     lib.dd_version.restype = C.c_char_p
     lib.dd_last_error.restype = C.c_char_p
+    _check_source_hash(lib)
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = C.c_int
     vp, i, l, f = C.c_void_p, C.c_int, C.c_long, C.c_float

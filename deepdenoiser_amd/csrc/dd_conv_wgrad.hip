@@ -743,9 +743,6 @@ int dispatch(const WgradP& p, hipStream_t stream) {
 
 }  // namespace
 
-bool dd_wgrad96_eligible(const dd_wgrad_args* a);
-int dd_wgrad96_launch(const dd_wgrad_args* a, hipStream_t stream);
-
 extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->p && a->q && a->out, "dd_conv_wgrad: null pointer");
   DD_REQUIRE(dd_dtype_ok(a->dtype), "dd_conv_wgrad: bad dtype %d", a->dtype);
@@ -759,8 +756,6 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "dd_conv_wgrad: empty grid");
   DD_REQUIRE(((uintptr_t)a->p % 16) == 0 && ((uintptr_t)a->q % 16) == 0, "dd_conv_wgrad: pointers must be 16-byte aligned");
   DD_REQUIRE(a->bias_mode >= 0 && a->bias_mode <= 2 && (a->bias_mode == 0 || a->bias_out), "dd_conv_wgrad: bias_mode=%d needs bias_out", a->bias_mode);
-  // 3x3 layers with 65..96 output channels: the whole gradient block in one workgroup, one pass over x and dy (csrc/dd_conv_wgrad96.hip)
-  if (dd_wgrad96_eligible(a)) return dd_wgrad96_launch(a, reinterpret_cast<hipStream_t>(stream));
   WgradP p;
   p.p = a->p; p.q = a->q; p.out = a->out; p.bias_out = a->bias_out; p.bias_mode = a->bias_mode;
   p.ldp = a->ldp; p.m = a->m; p.ldq = a->ldq; p.n = a->n; p.mv = mv; p.nv = nv;

@@ -5,7 +5,7 @@
 
 #include "dd_common.h"
 
-// ------------------------------------------------------------------------------------------------ errors / version
+// ------------------------------------------------------------------------------------------------ errors (dd_version: csrc/dd_version.hip)
 static thread_local char g_err[512] = "";
 void dd_set_error(const char* fmt, ...) {
   va_list ap;
@@ -14,7 +14,6 @@ void dd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* dd_last_error(void) { return g_err; }
-extern "C" const char* dd_version(void) { return "libdd_hip 0.1 (gfx950)"; }
 
 // CRC-32C, slicing-by-8 (host only).
 namespace {

@@ -424,8 +424,8 @@ class Graph:
             if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 64 and not in_relu and layer.cin >= 16
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0" and os.environ.get("DD_WGRAD_VIA_BWD", "1") != "0"):
                 # > 64 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair of 64 x 64
-                # channels (dx = NULL).  Measured faster than both dedicated weight-gradient kernels: 96->96 at 64x64 154 -> 115 us against
-                # csrc/dd_conv_wgrad96.hip, 128->128 at 32x32 71 -> 60 us against csrc/dd_conv_wgrad.hip
+                # channels (dx = NULL).  Measured faster than the dedicated weight-gradient kernel: 96->96 at 64x64 154 -> 115 us,
+                # 128->128 at 32x32 71 -> 60 us against csrc/dd_conv_wgrad.hip
                 self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, None, 0, 0, None, False, False, as_wgrad=True), "conv_wgrad"),
                          grad_params=[layer.kernel, layer.bias])
             else:
@@ -602,32 +602,5 @@ class Graph:
 
     def run(self, ops, stream=None):
         s = self.stream_ptr() if stream is None else stream
-        if stream is None and self.side_tags and any(getattr(op, "tag", "") in self.side_tags for op in ops):
-            return self._run_forked(ops)
         for op in ops:
             op(s)
-
-    # Launches whose tag is in `side_tags` (the weight gradients: nothing later in the step reads their output before the optimizer) go to a
-    # second HIP stream, forked by an event from the launch stream at their place in the program and joined at the end of the list.  The conv
-    # kernels are persistent one-workgroup-per-CU launches whose workgroups finish at different times (weights prologue, ragged tile counts,
-    # the atomic tail of a weight gradient): on one stream the next launch waits for the slowest workgroup; with the fork the other stream's
-    # workgroups fill the idle CUs.  Inside a hipGraph capture the events become graph edges.
-    side_tags = frozenset(t for t in os.environ.get("DD_SIDE_STREAM_TAGS", "").split(",") if t)
-
-    def _run_forked(self, ops):
-        main = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        side = self._side
-        used = False
-        for op in ops:
-            if getattr(op, "tag", "") in self.side_tags:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                op(side.cuda_stream)
-                used = True
-            else:
-                op(main.cuda_stream)
-        if used:
-            main.wait_stream(side)

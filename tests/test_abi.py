@@ -27,6 +27,14 @@ def test_version_and_error_strings(lib):
     assert isinstance(lib.dd_last_error(), bytes)
 
 
+def test_library_carries_the_hash_of_the_sources_next_to_it(lib):
+    """dd_version() ends in src=<sha256[:16] of csrc/* + include/dd_hip.h>: the prebuilt, git-ignored .so is provably built from this tree
+    (and _lib.load() refuses a stale one)."""
+    from deepdenoiser_amd import build
+    assert lib.dd_version().decode().endswith("src=" + build.source_hash())
+    assert _lib.source_hash() == build.source_hash()
+
+
 def test_invalid_arguments_return_status_not_exception(lib):
     a = _lib.ConvArgs()          # all-null
     assert lib.dd_conv_igemm(ctypes.byref(a), None) == -1

@@ -18,6 +18,6 @@ TG.check = show
 k, cin, cout, H, W = [int(v) for v in sys.argv[1:6]]
 dtype = sys.argv[6]
 B = int(sys.argv[7]) if len(sys.argv) > 7 else 1
-print("conv %dx%d %d->%d %dx%d B=%d %s  DD_CONV_RW=%s DD_FUSE_CONV_BWD=%s DD_WGRAD96=%s" % (k, k, cin, cout, H, W, B, dtype, os.environ.get("DD_CONV_RW", "1"),
-      os.environ.get("DD_FUSE_CONV_BWD", "1"), os.environ.get("DD_WGRAD96", "1")))
+print("conv %dx%d %d->%d %dx%d B=%d %s  DD_CONV_RW=%s DD_FUSE_CONV_BWD=%s" % (k, k, cin, cout, H, W, B, dtype, os.environ.get("DD_CONV_RW", "1"),
+      os.environ.get("DD_FUSE_CONV_BWD", "1")))
 TG._conv_case(engine, dtype, k, cin, cout, H, W, True, False, False, True, B=B)
