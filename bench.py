@@ -244,7 +244,12 @@ def main():
         local_rank = int(os.environ["DD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # DD_FORCE_COLLECTIVES=1: initialise the process group and issue every collective even in a world of ONE rank (launched through
+    # torch.distributed.run --nproc-per-node 1): the RCCL communicator, the side-stream all-reduces next to the captured hipGraph segments and
+    # the barriers of this file all run on a one-GPU box (tests/test_gpu_rccl.py).  Not a scaling measurement.
+    force_coll = os.environ.get("DD_FORCE_COLLECTIVES", "0") != "0"
+    use_dist = world > 1 or force_coll
+    if use_dist:
         import torch.distributed as dist
         backend = os.environ.get("DD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -264,12 +269,12 @@ def main():
     aj, tj = configs.cfg2_unet_kpcn(), configs.bench_training()
     arch = Architecture(aj, device=device, dtype=args.dtype, seed=2)       # identical init on every rank
     B, H, W = args.batch, args.tile, args.tile
-    trainer = Trainer(arch, tj, B, H, W, world_size=world, use_graph=not args.no_graph)
+    trainer = Trainer(arch, tj, B, H, W, world_size=world, use_graph=not args.no_graph, force_collectives=force_coll)
     feats, labels = synthetic_inputs(arch, B, H, W, device, seed=1000 + rank)    # per-rank data shard
     trainer.program.set_inputs(feats, labels)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -292,7 +297,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     loss = float(trainer.program.loss_buf)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -335,6 +340,9 @@ def main():
             "metric": "train tiles/sec (128x128x32ch U-Net KPCN)", "value": world * B * args.steps / dt, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            # physical devices behind the ranks: == n_gpus except under the DD_FORCE_DEVICE test hook (several ranks sharing one GPU)
+            "devices": 1 if os.environ.get("DD_FORCE_DEVICE") else world,
+            "collectives": (os.environ.get("DD_DIST_BACKEND", "nccl") if use_dist else None),
             "config": {"workload": "BASELINE config 2: U-Net [64,96,128]x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction, "
                                    "32-channel render-pass stack, %dx%d tiles, full training step (fwd+SMAPE loss+bwd+Adam)" % (H, W),
                        "tiles_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d" % world,
@@ -348,7 +356,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(aj, tj, H, W)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         barrier()                      # rank 0 may still be timing single launches for the roofline: leave together
         dist.destroy_process_group()
 

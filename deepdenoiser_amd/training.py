@@ -42,13 +42,16 @@ class GradientReducer:
     """Sum all-reduce of slices of the flat gradient arena, issued asynchronously (side HIP stream on GPU, async work handles on
     CPU/gloo) so that it overlaps the rest of backward.  `wait()` joins everything before the optimizer reads the arena."""
 
-    def __init__(self, grads, world_size, group=None):
+    def __init__(self, grads, world_size, group=None, force=False):
+        """force: issue the collectives even in a world of one rank (a one-rank RCCL communicator still runs its all-reduce kernel on the
+        side stream: how the RCCL code path is exercised on a one-GPU box, tests/test_gpu_rccl.py)."""
         self.grads, self.world, self.group = grads, world_size, group
-        self._stream = torch.cuda.Stream(device=grads.device) if (world_size > 1 and grads.is_cuda) else None
+        self.active = world_size > 1 or force
+        self._stream = torch.cuda.Stream(device=grads.device) if (self.active and grads.is_cuda) else None
         self._works = []
 
     def launch(self, lo, hi):
-        if self.world <= 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         import torch.distributed as dist
         view = self.grads[lo:hi]
@@ -75,19 +78,19 @@ class GradientReducer:
 
 
 class Trainer:
-    def __init__(self, arch, training_json, B, H, W, world_size=1, use_graph=True, n_buckets=4, force_segments=False):
+    def __init__(self, arch, training_json, B, H, W, world_size=1, use_graph=True, n_buckets=4, force_segments=False, force_collectives=False):
         self.arch, self.world = arch, world_size
         self.program = arch.program(B, H, W, training_json=training_json)
         self.use_graph = use_graph
-        self.n_buckets = max(1, n_buckets) if (world_size > 1 or force_segments) else 1
+        self.n_buckets = max(1, n_buckets) if (world_size > 1 or force_segments or force_collectives) else 1
         self._segments = None          # list of (ops, arena slice)
         self._graphs = None
-        self.reducer = GradientReducer(arch.params.grads, world_size)
+        self.reducer = GradientReducer(arch.params.grads, world_size, force=force_collectives)
         self._warm = 0
         # Masked means divide by the batch-GLOBAL mask count (Training.py:131-137).  With the batch sharded over ranks the per-rank counts
         # are summed (one all-reduce of a few dozen floats per step, before the forward) and divided by the world size: the optimizer
         # averages the ranks' gradients, so a rank's masked term must be  sum_rank(d * mask) * world / count_global.
-        self._reduce_masks = world_size > 1 and self.program.masked
+        self._reduce_masks = (world_size > 1 or force_collectives) and self.program.masked
         if self._reduce_masks:
             self.program.mask_reduce = self._mask_reduce
 

@@ -14,6 +14,13 @@ golden vectors) -- see tf_ops.py header and DESIGN.md.
 
 Trainable variables live in a VarStore that reproduces tf.variable_scope(reuse=...)
 + tf.layers auto-naming: creation order == first-use order.
+
+`storage="bf16" | "f16"` (default None = the reference's arithmetic) makes the restatement STORAGE-EMULATING: the same float64 graph, but
+every tensor the MI355X half-precision path keeps in HBM in its 2-byte storage type is rounded to that type at the point where it is
+stored -- the network input, the MFMA weight images, every conv / transposed-conv output, the partial sum of a conv over a skip concat
+(engine.Graph.conv split_at), the compose net's packed input -- and every activation GRADIENT is rounded where the reverse program stores
+it (after the ReLU-backward mask).  Nothing else changes (fp32/f64 accumulation, fp32 losses, softmax, blends), so the half-precision
+kernels can be gated against this oracle at summation-order tolerance instead of at the storage type's own error.
 """
 
 from collections import OrderedDict
@@ -21,6 +28,33 @@ from collections import OrderedDict
 import torch
 
 from . import tf_ops as T
+
+_STORAGE = {None: None, "f32": None, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+class _RoundForward(torch.autograd.Function):
+    """y = x rounded to the storage type; the gradient passes unchanged (the consumer's data-gradient launch reads the STORED value)."""
+
+    @staticmethod
+    def forward(ctx, x, st):
+        return x.to(st).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundBackward(torch.autograd.Function):
+    """y = x; the gradient is rounded to the storage type (a stored activation gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, st):
+        ctx.st = st
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.st).to(g.dtype), None
 
 # The pure-contract helpers (names / keys) are shared with the product package on purpose:
 # they are pinned separately against the reference's own modules (tests/golden/naming_golden.json).
@@ -31,8 +65,9 @@ from deepdenoiser_amd.render_passes import RenderPasses
 class VarStore:
     """Ordered variable store emulating TF variable scopes with reuse + per-scope layer counters."""
 
-    def __init__(self, dtype=torch.float64, seed=2):
+    def __init__(self, dtype=torch.float64, seed=2, storage=None):
         self.dtype = dtype
+        self.storage = _STORAGE[storage]
         self.vars = OrderedDict()
         self.gen = torch.Generator().manual_seed(seed)
         self._counters = {}
@@ -57,12 +92,42 @@ class VarStore:
         assert tuple(self.vars[name].shape) == tuple(shape), (name, self.vars[name].shape, shape)
         return self.vars[name]
 
-    def conv2d(self, scope, x, filters, k, relu):
+    # -- storage emulation (no-ops with storage=None)
+    def q(self, x):
+        """A stored activation: value rounded to the storage type."""
+        return x if self.storage is None else _RoundForward.apply(x, self.storage)
+
+    def qgrad(self, x):
+        """The point where the reverse program stores this tensor's gradient."""
+        return x if self.storage is None else _RoundBackward.apply(x, self.storage)
+
+    def _stored(self, pre, relu):
+        pre = self.qgrad(pre)                  # stored gradients are PRE-activation gradients: masked by the ReLU, then rounded
+        return self.q(torch.relu(pre) if relu else pre)
+
+    def conv2d(self, scope, x, filters, k, relu, res=None, split_at=None):
+        """tf.layers.conv2d(SAME) [+ res] [+ ReLU].  res / split_at only matter under storage emulation: the half-precision path rounds
+        conv + residual ONCE, and runs a 3x3 conv over a > 128-channel skip concat as conv(first part) -> stored partial sum ->
+        conv(second part) + partial sum (engine.Graph.conv)."""
         name = self._layer_name(scope, "conv2d")
         cin = x.shape[3]
         kernel = self.get(name + "/kernel", (k, k, cin, filters), fan_in=k * k * cin, fan_out=k * k * filters)
         bias = self.get(name + "/bias", (filters,))
-        return T.conv2d_same(x, kernel, bias, relu)
+        if self.storage is None:
+            y = T.conv2d_same(x, kernel, bias, False)
+            if res is not None:
+                y = y + res
+            return torch.relu(y) if relu else y
+        kq = self.q(kernel)
+        if (split_at is not None and k == 3 and res is None and cin > 128 and 0 < split_at < cin and split_at % 8 == 0
+                and max(split_at, cin - split_at) <= 128):
+            part = self.q(T.conv2d_same(x[..., :split_at], kq[:, :, :split_at], bias, False))
+            pre = T.conv2d_same(x[..., split_at:], kq[:, :, split_at:], None, False) + part
+        else:
+            pre = T.conv2d_same(x, kq, bias, False)
+            if res is not None:
+                pre = pre + res
+        return self._stored(pre, relu)
 
     def conv2d_transpose(self, scope, x, filters, k, relu):
         name = self._layer_name(scope, "conv2d_transpose")
@@ -70,7 +135,9 @@ class VarStore:
         # TF computes Glorot fans from the variable shape [k,k,out,in]: fan_in=k*k*out, fan_out=k*k*in
         kernel = self.get(name + "/kernel", (k, k, filters, cin), fan_in=k * k * filters, fan_out=k * k * cin)
         bias = self.get(name + "/bias", (filters,))
-        return T.conv2d_transpose_s2(x, kernel, bias, relu)
+        if self.storage is None:
+            return T.conv2d_transpose_s2(x, kernel, bias, relu)
+        return self._stored(T.conv2d_transpose_s2(x, self.q(kernel), bias, False), relu)
 
 
 # ----------------------------------------------------------------------------- backbones
@@ -79,9 +146,9 @@ def unet_predict(vs, scope, x, filters, convs_per_block, multiscale):
     steps = len(filters) - 1
     results, skips = [], []
 
-    def block(x, f):
-        for _ in range(convs_per_block):
-            x = vs.conv2d(scope, x, f, 3, relu=True)           # UNet.py:25-36
+    def block(x, f, split_at=None):
+        for c in range(convs_per_block):
+            x = vs.conv2d(scope, x, f, 3, relu=True, split_at=split_at if c == 0 else None)           # UNet.py:25-36
         return x
 
     for i in range(steps):
@@ -90,12 +157,12 @@ def unet_predict(vs, scope, x, filters, convs_per_block, multiscale):
         x = T.max_pool_same(x, 3, 2)                            # UNet.py:38-52
     for i in range(steps):
         index = steps - i
-        x = block(x, filters[index])
+        x = block(x, filters[index], split_at=filters[index] if i > 0 else None)     # [skip | upsampled]: filters[index] channels each
         if multiscale:
             results.append(x)
         x = vs.conv2d_transpose(scope, x, filters[index - 1], 2, relu=True)   # UNet.py:54-59
         x = torch.cat([skips[index - 1], x], dim=3)             # UNet.py:91-92
-    x = block(x, filters[0])
+    x = block(x, filters[0], split_at=filters[0])
     results.append(x)
     return results
 
@@ -133,13 +200,11 @@ def tiramisu_predict(vs, scope, x, filters, convs_per_block, multiscale):
 def compose_scales(vs, scope, small, fine):
     """MultiScalePrediction.compose_scales (:36-54) with its weight net (:57-93)."""
     small = T.resize_nearest_x2(small)
-    x = torch.cat([small, fine], dim=3)
+    x = vs.q(vs.qgrad(torch.cat([small, fine], dim=3)))      # (storage emulation: the net reads the packed 6-channel input in the storage type)
     x = vs.conv2d(scope, x, 24, 1, relu=True)
     for _ in range(2):
-        r = x
-        for _ in range(2):
-            r = vs.conv2d(scope, torch.relu(r), 24, 3, relu=False)
-        x = x + 1.0 * r
+        r = vs.conv2d(scope, torch.relu(x), 24, 3, relu=False)
+        x = vs.conv2d(scope, torch.relu(r), 24, 3, relu=False, res=x)      # x + 1.0 * r (MultiScalePrediction.py:81-93)
     x = vs.conv2d(scope, x, 1, 1, relu=True)
     wts = torch.sigmoid(x)
     low = T.resize_nearest_x2(T.avg_pool_same(fine, 2))
@@ -171,9 +236,9 @@ class _Feature:
 class OracleArchitecture:
     """Restatement of Architecture.__init__ (:343-535) + predict (:537-617)."""
 
-    def __init__(self, parsed_json, dtype=torch.float64, seed=2):
+    def __init__(self, parsed_json, dtype=torch.float64, seed=2, storage=None):
         self.dtype = dtype
-        self.vs = VarStore(dtype, seed)
+        self.vs = VarStore(dtype, seed, storage)
         self.sources_per_target = parsed_json["number_of_sources_per_target"]
         arch = parsed_json["architecture"]
         self.tuple_type = arch["source_encoder"]["feature_prediction_tuple_type"]
@@ -266,7 +331,7 @@ class OracleArchitecture:
             self._prepare(f, features)
         internals = {}
         for tname, members in self.tuples:
-            x = self._network_input(tname, members, features)
+            x = vs.q(vs.qgrad(self._network_input(tname, members, features)))
             internals.setdefault("network_input", []).append(x)
             scope = "reused_core_architecture"
             vs.enter_scope(scope)

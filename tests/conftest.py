@@ -16,3 +16,19 @@ def pytest_configure(config):
 def lib():
     from deepdenoiser_amd import _lib
     return _lib.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Every oracle comparison of a -m gpu session with its measured error and its gate -> gpurun_out/parity_errors.txt (copied to profiles/)."""
+    try:
+        import gpu_util
+    except Exception:
+        return
+    if not gpu_util.RECORDS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.txt"), "w") as f:
+        f.write("# test | compared tensor | measured rel-L2 (or scalar) | gate | measured/gate\n")
+        for test, name, e, tol in gpu_util.RECORDS:
+            f.write("%s | %s | %.3e | %.1e | %.2f%s\n" % (test, name, e, tol, e / tol if tol else 0.0, "  <-- OVER" if e > tol else ""))

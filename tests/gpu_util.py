@@ -1,7 +1,23 @@
 """Helpers shared by the -m gpu tests (HIP path vs the CPU oracle)."""
 import torch
 
+import os
+
+# Gates by what an output IS, not by which path produced it:
+#   TOL    a whole half-precision network against the PLAIN f64 oracle: the storage type's own accumulated error;
+#   ROUND  a storage-type output (y, dx) computed from inputs that are representable in the storage type, or any tensor compared with the
+#          storage-emulating oracle (oracle.model, storage=...): one rounding is rel-L2 ~ 2^-9/sqrt(3) = 1.1e-3 (bf16), 2^-12/sqrt(3) =
+#          1.4e-4 (fp16) -- gated at <= 2 roundings' worth so that a 1-ulp flip on a rounding boundary passes and a dropped channel, tap or
+#          halo column (>= 1/192 of the terms = 5e-3 relative at the very least) does not;
+#   ACC32  an fp32 output (dW, db, kernel-prediction output) computed from representable inputs: bf16 x bf16 products are exact in fp32, so
+#          only the fp32 summation order differs from the f64 oracle.
 TOL = {"f32": 3e-5, "bf16": 2.5e-2, "f16": 3.5e-3}
+ROUND = {"f32": 3e-5, "bf16": 4e-3, "f16": 5e-4}
+ACC32 = {"f32": 3e-5, "bf16": 1e-4, "f16": 1e-4}
+
+# every comparison of the session: (test id, name, measured rel-L2, gate); tests/conftest.py writes them to gpurun_out/parity_errors.txt
+RECORDS = []
+REPORT_ONLY = os.environ.get("DD_PARITY_REPORT", "0") != "0"      # measure everything, fail nothing (how the gates were set)
 
 
 def rel_l2(a, b):
@@ -13,6 +29,9 @@ def check(name, got, want, tol):
     assert tuple(got.shape) == tuple(want.shape), (name, tuple(got.shape), tuple(want.shape))
     assert torch.isfinite(got.double()).all(), name + ": non-finite values"
     e = rel_l2(got, want)
+    RECORDS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], name, e, tol))
+    if REPORT_ONLY:
+        return e
     assert e <= tol, "%s: rel-L2 %.3e > %.1e (max abs diff %.3e, |want| max %.3e)" % (
         name, e, tol, float((got.double().cpu() - want.double().cpu()).abs().max()), float(want.double().abs().max()))
     return e
@@ -38,3 +57,11 @@ def read(dt):
 
 def set_param(ps, p, value):
     ps.value(p).copy_(value.to(torch.float32))
+
+
+def gate(name, value, bound):
+    """A scalar bound (loss error, median / max over tensors) recorded like check()."""
+    RECORDS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], name, float(value), float(bound)))
+    if not REPORT_ONLY:
+        assert value <= bound, "%s: %.3e > %.1e" % (name, value, bound)
+    return value

@@ -1,5 +1,7 @@
 """-m gpu: hand-written HIP kernels (through the C-ABI + engine) vs the CPU oracle, op by op.
-f32 path: exact-f32 MFMA => tolerance 3e-5 rel-L2; bf16 path: bf16 storage, fp32 accumulate => 2.5e-2; fp16 storage => 3.5e-3."""
+Inputs, weights and upstream gradients are REPRESENTABLE in the storage type, so every product is exact in fp32 and the gates are set by what
+an output is (tests/gpu_util.py): storage-type outputs (y, dx) within one-to-two roundings (ROUND: bf16 4e-3, fp16 5e-4), fp32 outputs
+(dW, db, kernel-prediction output) within fp32 summation order (ACC32: 1e-4 for bf16 and fp16 alike), the f32 path 3e-5 throughout."""
 import ctypes
 
 import numpy as np
@@ -7,7 +9,7 @@ import pytest
 import torch
 
 from oracle import tf_ops as T
-from gpu_util import TOL, check, fill, read, rel_l2, representable, set_param
+from gpu_util import ACC32, ROUND, TOL, check, fill, read, rel_l2, representable, set_param
 
 pytestmark = pytest.mark.gpu
 
@@ -150,8 +152,7 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
     if residual:
         pre = pre + ro
     yo = torch.relu(pre) if relu else pre
-    tol = TOL[dtype]
-    check("y", read(y), yo.detach(), tol)
+    check("y", read(y), yo.detach(), ROUND[dtype])
     # pad channels must be exactly zero
     assert float(y.buf[..., y.C:y.Cp].abs().max() if y.Cp > y.C else 0) == 0.0
 
@@ -164,11 +165,11 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
     torch.cuda.synchronize()
     gx_want = grads[0] * (xv > 0) if (x_relu or in_relu) else grads[0]
     if x_requires_grad:
-        check("dx", read(x.grad()), gx_want, tol * 2)
-    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
-    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
+        check("dx", read(x.grad()), gx_want, ROUND[dtype])
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], ACC32[dtype])
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], ACC32[dtype])
     if residual:
-        check("dres", read(res.grad()), grads[3], tol)
+        check("dres", read(res.grad()), grads[3], ROUND[dtype])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -197,22 +198,29 @@ def test_conv_grad_accumulation_and_concat_views(eng, dtype, f, H, W):
         ws.append(w.clone().requires_grad_(True))
     fill(x, xv)
     g.run(g.pack_ops); g.run(g.fwd_ops)
+    # the oracle chain with the storage roundings of the half-precision path (oracle.model.VarStore.q / qgrad): the stored concat is
+    # rounded, its gradient is masked and then rounded, x's gradient is the rounded sum of two rounded contributions
+    from oracle.model import VarStore
+    emu = VarStore(storage=dtype)
     xo = xv.clone().requires_grad_(True)
-    co = torch.cat([T.conv2d_same(xo, ws[0], None, True), T.conv2d_same(xo, ws[1], None, True)], dim=3)
+    xin = emu.qgrad(xo)
+
+    def stored(pre):
+        return emu.q(torch.relu(emu.qgrad(pre)))
+    co = torch.cat([stored(T.conv2d_same(xin, ws[0], None, False)), stored(T.conv2d_same(xin, ws[1], None, False))], dim=3)
     zo = T.conv2d_same(co, ws[2], None, False)
-    tol = TOL[dtype]
-    check("cat", read(cat), co.detach(), tol)
-    check("z", read(z), zo.detach(), tol * 2)
+    check("cat", read(cat), co.detach(), ROUND[dtype])
+    check("z", read(z), zo.detach(), ROUND[dtype])
     G = representable(torch.randn(zo.shape, generator=gen, dtype=torch.float64), dtype)
     fill(z.grad(), G)
-    # the stored activations are rounded to the graph dtype; differentiate the oracle at the same point
     grads = torch.autograd.grad((zo * G).sum(), [xo] + ws)
     g.params.grads.zero_()
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
-    check("dx(accumulated)", read(x.grad()), grads[0] * (xv > 0), tol * 4)
+    # first writer rounds, second writer reads that, adds and rounds again (the oracle rounds the f64 sum once): <= 2 roundings
+    check("dx(accumulated)", read(x.grad()), grads[0] * (xv > 0), 2 * ROUND[dtype])
     for lay, gw in zip((l1, l2, l3), grads[1:]):
-        check("dW " + lay.name, g.params.grad(lay.kernel).double().cpu(), gw, tol * 4)
+        check("dW " + lay.name, g.params.grad(lay.kernel).double().cpu(), gw, 3 * ACC32[dtype])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -236,8 +244,7 @@ def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
     g.run(g.pack_ops); g.run(g.fwd_ops)
     xo, wo, bo = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
     pre = T.conv2d_transpose_s2(xo, wo, bo, False)
-    tol = TOL[dtype]
-    check("y", read(y), torch.relu(pre).detach(), tol)
+    check("y", read(y), torch.relu(pre).detach(), ROUND[dtype])
     assert float(cat.buf[..., :cout].abs().max()) == 0.0       # the skip half of the concat buffer is untouched
     G = torch.randn(pre.shape, generator=gen, dtype=torch.float64)
     gpre = representable(G * (pre.detach() > 0), dtype)
@@ -246,9 +253,9 @@ def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
     g.params.grads.zero_()
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
-    check("dx", read(x.grad()), grads[0] * (xv > 0), tol * 2)
-    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
-    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
+    check("dx", read(x.grad()), grads[0] * (xv > 0), ROUND[dtype])
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], ACC32[dtype])
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], ACC32[dtype])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -270,8 +277,7 @@ def test_conv_transpose_3x3(eng, dtype):
     g.run(g.pack_ops); g.run(g.fwd_ops)
     xo, wo, bo = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
     pre = T.conv2d_transpose_s2(xo, wo, bo, False)
-    tol = TOL[dtype]
-    check("y", read(y), torch.relu(pre).detach(), tol)
+    check("y", read(y), torch.relu(pre).detach(), ROUND[dtype])
     G = torch.randn(pre.shape, generator=gen, dtype=torch.float64)
     gpre = representable(G * (pre.detach() > 0), dtype)
     fill(y.grad(), gpre)
@@ -279,9 +285,9 @@ def test_conv_transpose_3x3(eng, dtype):
     g.params.grads.zero_()
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
-    check("dx", read(x.grad()), grads[0], tol * 2)
-    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], tol * 2)
-    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], tol * 2)
+    check("dx", read(x.grad()), grads[0], ROUND[dtype])
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], ACC32[dtype])
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], ACC32[dtype])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -334,7 +340,7 @@ def test_kernel_prediction_apply(lib, eng, dtype, ks):
     dl = torch.full((B, H, W, ld), 7.0, dtype=tdt).cuda()
     L.check(lib.dd_kpcn_bwd(src.data_ptr(), 4, lgd.data_ptr(), ld, G.cuda().data_ptr(), 3, dl.data_ptr(), ld, ld, B, H, W, ks, code, None))
     torch.cuda.synchronize()
-    check("kp dlogits", dl[..., :k2].cpu(), gl, {"f32": 2e-5, "bf16": 1e-2, "f16": 2e-3}[dtype])
+    check("kp dlogits", dl[..., :k2].cpu(), gl, ROUND[dtype])
     assert float(dl[..., k2:].float().abs().max()) == 0.0
 
 

@@ -1,0 +1,119 @@
+"""-m gpu: the half-precision kernels the bench actually runs, gated at the precision of their arithmetic.
+
+The plain f64 oracle can only bound a bf16 / fp16 network by the storage type's own accumulated error (1e-2 forward, 3.5e-2 median per
+gradient tensor at full size): a kernel that drops a channel or a halo column hides under that.  The STORAGE-EMULATING oracle
+(oracle.model.OracleArchitecture(storage=...)) is the same float64 graph with every tensor the half-precision path keeps in HBM rounded
+where it is stored, and every activation gradient rounded where the reverse program stores it.  Against it the fused head / compose /
+fused-backward / register-weight / transposed-conv kernels differ only by fp32 summation order and by the occasional 1-ulp flip on a
+rounding boundary, so predictions, loss and EVERY parameter gradient (max, not median) are gated one to two orders of magnitude tighter.
+"""
+import pytest
+import torch
+
+from deepdenoiser_amd import configs
+from gpu_util import check, gate, rel_l2
+from oracle import training as OT
+from oracle.model import OracleArchitecture
+from test_gpu_model import CASES, _inputs, _with_flags
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _emulated_step(aj, tj, dtype, feats, labels, loss_scale):
+    """Predictions, loss and parameter gradients of the storage-emulating oracle.  The stored gradients of the fp16 path are `loss_scale`
+    times larger (program.Program.loss_scale): the emulation rounds the scaled gradients and divides the result."""
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2, storage=dtype)
+    preds = oracle.predict(feats)
+    loss = OT.model_loss(oracle, aj, tj, preds, labels)
+    params = oracle.parameters()
+    grads = torch.autograd.grad(loss * loss_scale, params, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g / loss_scale for g, p in zip(grads, params)]
+    return oracle, [{k: v.detach() for k, v in d.items()} for d in preds], float(loss), grads
+
+
+def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate):
+    from deepdenoiser_amd.architecture import Architecture
+    plain = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    feats, labels = _inputs(plain, B, H, W)
+    feats = _with_flags(aj, feats, B, H, W)
+    arch = Architecture(aj, device="cuda", dtype=dtype)
+    prog = arch.program(B, H, W, training_json=tj)
+    oracle, preds_o, loss_o, grads_o = _emulated_step(aj, tj, dtype, feats, labels, prog.loss_scale)
+    assert [p.name for p in arch.params.params] == list(oracle.vs.vars.keys())
+    arch.params.load_list(list(oracle.vs.vars.values()))
+    dev, devl = {k: v.cuda() for k, v in feats.items()}, {k: v.cuda() for k, v in labels.items()}
+    loss = float(prog.train_step(dev, devl))
+    torch.cuda.synchronize()
+    preds = prog.prediction_dictionaries()
+    worst = 0.0
+    for s, (dp, do) in enumerate(zip(preds, preds_o)):
+        for k in do:
+            assert torch.isfinite(dp[k]).all()
+            worst = max(worst, check("%s %s scale %d %s" % (what, dtype, s, k), dp[k].cpu(), do[k], fwd_gate))
+    gate("%s %s loss rel err" % (what, dtype), abs(loss - loss_o) / abs(loss_o), loss_gate)
+    errs = []
+    for p, go in zip(arch.params.params, grads_o):
+        got = arch.params.grad(p).double().cpu() / prog.loss_scale
+        if float(go.norm()) == 0.0:
+            assert float(got.abs().max()) < 1e-6, p.name
+            continue
+        errs.append((rel_l2(got, go), p.name))
+    errs.sort()
+    med, (mx, mx_name) = errs[len(errs) // 2][0], errs[-1]
+    print("%s, %s storage vs the storage-emulating oracle: forward worst rel-L2 %.3e, loss rel err %.2e, gradient rel-L2 median %.3e max %.3e (%s) over %d tensors"
+          % (what, dtype, worst, abs(loss - loss_o) / abs(loss_o), med, mx, mx_name, len(errs)))
+    gate("%s %s gradient median" % (what, dtype), med, grad_median_gate)
+    gate("%s %s gradient max (%s)" % (what, dtype, mx_name), mx, grad_max_gate)
+    assert torch.isfinite(arch.params.grads).all()
+    return errs
+
+
+# measured (profiles/r03_parity_errors.txt); each gate ~2x the measured value
+FULL_SIZE_GATES = {"bf16": (2e-3, 5e-4, 4e-3, 2e-2), "f16": (3e-4, 1e-4, 6e-4, 4e-3)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_cfg2_full_size_half_precision_against_the_storage_emulating_oracle(dtype):
+    """The bench's configuration (cfg-2, 128x128, real filters, 5x5 kernel prediction, 3 scales) at B = 2 -- batch striding on every round-2
+    kernel: register-weight forward, fused 3x3 backward, weight-gradient role, transposed-conv, fused head and compose kernels."""
+    _need_gpu()
+    aj, tj = configs.cfg2_unet_kpcn(), configs.bench_training()
+    _compare("cfg-2 128x128 B=2", dtype, aj, tj, 2, 128, 128, *FULL_SIZE_GATES[dtype])
+
+
+SMALL_GATES = {"bf16": (4e-3, 1e-3, 1e-2, 5e-2), "f16": (5e-4, 2e-4, 2e-3, 1e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", ["example_json_single_embedding", "cfg2_unet_kpcn_real_filters", "combined_tuples_kp3", "tiramisu_multiscale",
+                                  "ragged_tile_three_scales", "one_hot_no_multiscale_raw_kp_source", "invert_before_multiscale"])
+def test_small_networks_half_precision_against_the_storage_emulating_oracle(case, dtype):
+    """Every structural variant of tests/test_gpu_model.py on the half-precision path: fused head with 3x3 / 5x5 kernels, layer-wise head for
+    COMBINED tuples, compose net on ragged tiles, Tiramisu's dense concats and 3x3/s2 transposed convs, embedding gradients."""
+    _need_gpu()
+    aj, B, H, W = CASES[case]
+    single_feature = len(aj["combined_features"]) == 1
+    tj = configs.bench_training() if single_feature else configs.training()
+    _compare(case, dtype, aj, tj, B, H, W, *SMALL_GATES[dtype])
+
+
+@pytest.mark.parametrize("dtype,grad_median_gate,grad_max_gate", [("bf16", 0.045, 0.16), ("f16", 0.016, 0.055)])
+def test_half_precision_full_size_error_against_the_plain_oracle_max_gated(dtype, grad_median_gate, grad_max_gate):
+    """The storage type's OWN error at full size (cfg-2, 128x128, B = 1) against the plain f64 oracle, with the maximum over the 68 gradient
+    tensors gated as well as the median (round 2 printed it: bf16 1.08e-1, fp16 3.6e-2)."""
+    _need_gpu()
+    from test_gpu_model import _pair
+    aj, tj, B, H, W = configs.cfg2_unet_kpcn(), configs.bench_training(), 1, 128, 128
+    oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, dtype, B, H, W, tj)
+    loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    prog.train_step(dev, devl)
+    torch.cuda.synchronize()
+    errs = sorted(rel_l2(arch.params.grad(p).cpu() / prog.loss_scale, go) for p, go in zip(arch.params.params, grads_o) if float(go.norm()) > 0)
+    print("%s storage vs the plain oracle, cfg-2 128x128: gradient rel-L2 median %.3e max %.3e" % (dtype, errs[len(errs) // 2], errs[-1]))
+    gate("%s plain-oracle gradient median" % dtype, errs[len(errs) // 2], grad_median_gate)
+    gate("%s plain-oracle gradient max" % dtype, errs[-1], grad_max_gate)
