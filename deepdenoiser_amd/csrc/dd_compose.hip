@@ -399,6 +399,21 @@ struct ComposeBwdP {
 constexpr int NFPB = 144 + 24;       // fp32 parameters of the backward kept in LDS: w_in (rounded), w_out (rounded)
 constexpr int LDS_BWD = 4 * WL_BYTES + 3 * BUF_BYTES + 256 * 4 * 4 + 256 * 6 * 4 + 256 * 4 + NFPB * 4;
 
+// 12 waves (3 per SIMD, 168 registers each): 6 data-gradient + 6 weight-gradient.  Round 2 shipped 16 waves (4 per SIMD, 128 registers: 8 + 8),
+// which hipcc could only build with 37 spilled registers -- 176 bytes of scratch per lane, 305 MB of scratch writes per launch against 20 MB
+// of algorithmic output (profiles/r02_j_pmc_WRITE_SIZE.txt).  CB_WAVES=16 still builds that geometry for A/B runs (tools/build_variant.sh).
+#ifndef CB_WAVES
+#define CB_WAVES 12
+#endif
+constexpr int BWD_WAVES = CB_WAVES, BWD_THREADS = BWD_WAVES * 64;
+constexpr int DG_WAVES = BWD_WAVES / 2, DG_THREADS = DG_WAVES * 64;      // data-gradient role: waves 0 .. DG_WAVES - 1
+constexpr int WG_NT = CB_WAVES == 16 ? 5 : 3, WG_NJ = CB_WAVES == 16 ? 1 : 2;
+static_assert(CB_WAVES == 12 || CB_WAVES == 16, "compose backward: 12 or 16 waves");
+// S5: threads 0..255 (data-gradient role) take one interior pixel each; 384 threads take the two 1x1 layers' weight gradients: 256..639 with
+// 16 waves (half of them in either role), the whole weight-gradient role with 12
+constexpr int W1_FIRST = CB_WAVES == 16 ? 256 : DG_THREADS;
+static_assert(DG_THREADS >= 256 && W1_FIRST + 384 <= BWD_THREADS, "S5 thread assignment");
+
 typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
 
 // Transposed MFMA fragment of a [pixel][24 channel] frame: the 8 k-values (pixels) of channel `lane & 15` of channel tile `ctile` for the
@@ -418,21 +433,24 @@ __device__ __forceinline__ uint4 frame_frag_tr(const char* frame, int kst, int s
   return r;
 }
 
-// Weight gradient of one 3x3 layer for this tile's 256 interior pixels: acc[i] += act[p + tap_i] (x) dc[p].
-// A weight-gradient wave owns input-channel tile mi, output-channel tile nj and tap group tg (0: taps 0..4, 1: taps 5..8).
-template <typename T, bool RELU_A>
-__device__ __forceinline__ void wgrad_stage(f32x4_t (&acc)[5], const char* act, const char* dc, int mi, int nj, int tg, int lane) {
+// Weight gradient of one 3x3 layer for this tile's 256 interior pixels: acc[i * NJ + j] += act[p + tap_i] (x) dc[p] for the wave's NT taps
+// (tap0 .. tap0 + NT - 1, those beyond 8 idle) and NJ output-channel tiles (nj0 .. nj0 + NJ - 1) of input-channel tile mi.
+//   16 waves: 8 weight-gradient waves = (mi, nj, tap group of 5): NT = 5, NJ = 1, 20 accumulator tiles per wave;
+//   12 waves: 6 weight-gradient waves = (mi, tap group of 3), both output-channel tiles: NT = 3, NJ = 2, 24 tiles per wave, 5 fragment
+//             reads per 6 MFMAs instead of 6 per 5.
+template <typename T, bool RELU_A, int NT, int NJ>
+__device__ __forceinline__ void wgrad_stage(f32x4_t (&acc)[NT * NJ], const char* act, const char* dc, int mi, int nj0, int tap0, int lane) {
   const uint32_t one2 = pack2<T>(1.f, 1.f);
-  const bool ones_lane = mi == 1 && tg == 0 && (lane & 15) == 8;      // channel 24 := 1  =>  row 24 of the centre-tap tile = bias gradient
+  const bool ones_lane = mi == 1 && (lane & 15) == 8;      // channel 24 := 1  =>  row 24 of the centre-tap tile = bias gradient
   // this lane's part of every transposed fragment read (frame_frag_tr): pixel (g >> 1, (g & 1) * 8 + (t16 >> 2)) of the k-step, channel quad
   // t16 & 3; k-step and the +4-pixel second half are immediates on top of a few address registers
   const int t16 = lane & 15, g = lane >> 4;
   const int loff = ((4 + (g >> 1)) * FR + 4 + (g & 1) * 8 + (t16 >> 2)) * PIXB + (t16 & 3) * 8;
-  const char* pq = dc + loff + nj * 32;
-  const char* pa[5];
+  const char* pq = dc + loff + nj0 * 32;
+  const char* pa[NT];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int tap = min(tg * 5 + i, 8);
+  for (int i = 0; i < NT; ++i) {
+    const int tap = min(tap0 + i, 8);
     pa[i] = act + loff + mi * 32 + ((tap / 3 - 1) * FR + (tap % 3 - 1)) * PIXB;
   }
   auto tr = [](const char* a) {
@@ -445,42 +463,68 @@ __device__ __forceinline__ void wgrad_stage(f32x4_t (&acc)[5], const char* act, 
     r.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
     return r;
   };
+  constexpr int GRP = NT > 3 ? 3 : NT;      // fragments in flight at a time
 #pragma unroll 1
   for (int kst = 0; kst < 8; ++kst) {
     const int koffs = kst * 2 * FR * PIXB;
-    const uint4 bq = tr(pq + koffs);
+    uint4 bq[NJ];
 #pragma unroll
-    for (int i0 = 0; i0 < 5; i0 += 3) {             // 3 + 2 fragments at a time: 80 accumulator registers leave room for little else
-      uint4 ap[3];
+    for (int j = 0; j < NJ; ++j) bq[j] = tr(pq + j * 32 + koffs);
 #pragma unroll
-      for (int i = i0; i < i0 + 3 && i < 5; ++i) {
+    for (int i0 = 0; i0 < NT; i0 += GRP) {
+      uint4 ap[GRP];
+#pragma unroll
+      for (int i = i0; i < i0 + GRP && i < NT; ++i) {
         ap[i - i0] = tr(pa[i] + koffs);
         if (RELU_A) ap[i - i0] = relu16<T>(ap[i - i0]);
-        if (i == 4 && ones_lane) ap[i - i0] = uint4{one2, one2, one2, one2};      // tap group 0, slot 4 = the centre tap
+        if (ones_lane && tap0 + i == 4) ap[i - i0] = uint4{one2, one2, one2, one2};
       }
 #pragma unroll
-      for (int i = i0; i < i0 + 3 && i < 5; ++i)
-        if (i < 4 || tg == 0) acc[i] = mma16<T>(ap[i - i0], bq, acc[i]);
+      for (int i = i0; i < i0 + GRP && i < NT; ++i)
+        if (tap0 + i <= 8) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i * NJ + j] = mma16<T>(ap[i - i0], bq[j], acc[i * NJ + j]);
+        }
     }
   }
 }
 
 // Data gradient of one 3x3 layer on the frame (the forward's geometry: reads `in` on [L-1, 25-L)^2, writes `out` on [L, 24-L)^2),
-// run by the eight data-gradient waves (w8 = 0..7).
+// run by the DG_WAVES data-gradient waves (w8 = 0 .. DG_WAVES - 1).
 //   MODE 0: out = conv . [mask > 0]       MODE 1: out = res + conv . [mask > 0]       MODE 2: out = (res + conv) . [mask > 0]
+// 16 waves (128 registers per wave): the weight fragments are re-read from LDS for every chunk, two K-chunks ahead of their MFMAs;
+// 12 waves (168 registers): the layer's 14 weight fragments stay in registers for the whole stage (a chunk then reads 7 operand vectors
+// from LDS instead of 21).
 template <typename T, int L, int MODE>
 __device__ __forceinline__ void dgrad_layer(const char* in, char* out, const char* res, const char* mask, const char* wl,
                                             const int (&koff)[NCHUNK], int w8, int li, int q) {
   constexpr int R = FR - 2 * L, NPIX = R * R, CHUNKS = (NPIX + 15) / 16;
-  // (4 waves per SIMD = 128 registers per wave: the weight fragments are re-read from LDS for every chunk, two K-chunks ahead of their MFMAs)
   const char* w0 = wl + w_off(li, q);
   const char* w1 = wl + w_off(16 + li, q);
-  for (int chunk = w8; chunk < CHUNKS; chunk += 8) {
+#if CB_WAVES == 12
+  uint4 wfa[NCHUNK], wfb[NCHUNK];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    wfa[c] = *reinterpret_cast<const uint4*>(w0 + c * 2048);
+    wfb[c] = *reinterpret_cast<const uint4*>(w1 + c * 2048);
+  }
+#endif
+  for (int chunk = w8; chunk < CHUNKS; chunk += DG_WAVES) {
     const int P = chunk * 16 + li;
     const int Pc = P < NPIX ? P : NPIX - 1;
     const int y = Pc / R, x = Pc - y * R;
     const char* base = in + ((L - 1 + y) * FR + (L - 1 + x)) * PIXB;
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#if CB_WAVES == 12
+    uint4 bf[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) bf[c] = *reinterpret_cast<const uint4*>(base + koff[c]);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      a0 = mma16<T>(wfa[c], bf[c], a0);
+      a1 = mma16<T>(wfb[c], bf[c], a1);
+    }
+#else
     uint4 bf[3], wa[3], wb[3];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -500,6 +544,7 @@ __device__ __forceinline__ void dgrad_layer(const char* in, char* out, const cha
       a1 = mma16<T>(wb[c % 3], bf[c % 3], a1);
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     const int po = ((L + y) * FR + (L + x)) * PIXB;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -520,33 +565,43 @@ __device__ __forceinline__ void dgrad_layer(const char* in, char* out, const cha
 }
 
 // Activation frame of one stage: region [LO, 24-LO)^2 of the 24x24 frame, 3 x 16 bytes per pixel, zeros outside the image.
-constexpr int BWD_THREADS = 1024;      // 16 waves: 8 data-gradient + 8 weight-gradient (4 per SIMD; every phase of this kernel is latency-bound)
+// The frame-copy / per-pixel index arithmetic depends on the thread index only: left alone, hipcc hoists it out of the tile loop for all four
+// activation regions at once and pays for it with dozens of live registers (then spills around the MFMA stages).  An opaque copy of the thread
+// index per use keeps each piece of address arithmetic next to its loads and stores.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 template <int LO> struct ActRegion { static constexpr int R = FR - 2 * LO, NV = R * R * 3, ITERS = (NV + BWD_THREADS - 1) / BWD_THREADS; };
+// (pre0 / pre1 are two plain registers-quads: as a uint4[2] array indexed by the unrolled loop they were kept in scratch memory)
 template <int LO>
-__device__ __forceinline__ void act_load(uint4 (&pre)[2], const void* src, int ld, int b, int y0, int x0, int H, int W, int tid) {
+__device__ __forceinline__ uint4 act_load_one(const char* base, const char* zero, int ld, int b, int y0, int x0, int H, int W, int v) {
   constexpr int R = ActRegion<LO>::R, NV = ActRegion<LO>::NV;
-  const char* base = reinterpret_cast<const char*>(src);
-  const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
-#pragma unroll
-  for (int it = 0; it < ActRegion<LO>::ITERS; ++it) {
-    const int v = tid + it * BWD_THREADS;
-    const int px = v / 3, slot = v - px * 3;
-    const int fy = LO + px / R, fx = LO + px % R;
-    const int gy = y0 - 4 + fy, gx = x0 - 4 + fx;
-    const bool ok = v < NV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    pre[it] = *reinterpret_cast<const uint4*>(ok ? base + (((long)b * H + gy) * W + gx) * ld * 2 + slot * 16 : zero);
-  }
+  const int px = v / 3, slot = v - px * 3;
+  const int fy = LO + px / R, fx = LO + px % R;
+  const int gy = y0 - 4 + fy, gx = x0 - 4 + fx;
+  const bool ok = v < NV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+  return *reinterpret_cast<const uint4*>(ok ? base + (((long)b * H + gy) * W + gx) * ld * 2 + slot * 16 : zero);
 }
 template <int LO>
-__device__ __forceinline__ void act_store(char* buf, const uint4 (&pre)[2], int tid) {
+__device__ __forceinline__ void act_load(uint4& pre0, uint4& pre1, const void* src, int ld, int b, int y0, int x0, int H, int W, int tid) {
+  static_assert(ActRegion<LO>::ITERS <= 2, "two prefetch registers-quads per thread");
+  const char* base = reinterpret_cast<const char*>(src);
+  const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
+  tid = opaque(tid);
+  pre0 = act_load_one<LO>(base, zero, ld, b, y0, x0, H, W, tid);
+  if (ActRegion<LO>::ITERS > 1) pre1 = act_load_one<LO>(base, zero, ld, b, y0, x0, H, W, tid + BWD_THREADS);
+}
+template <int LO>
+__device__ __forceinline__ void act_store_one(char* buf, const uint4& pre, int v) {
   constexpr int R = ActRegion<LO>::R, NV = ActRegion<LO>::NV;
-#pragma unroll
-  for (int it = 0; it < ActRegion<LO>::ITERS; ++it) {
-    const int v = tid + it * BWD_THREADS;
-    const int px = v / 3, slot = v - px * 3;
-    const int fy = LO + px / R, fx = LO + px % R;
-    if (v < NV) *reinterpret_cast<uint4*>(buf + (fy * FR + fx) * PIXB + slot * 16) = pre[it];
-  }
+  const int px = v / 3, slot = v - px * 3;
+  const int fy = LO + px / R, fx = LO + px % R;
+  if (v < NV) *reinterpret_cast<uint4*>(buf + (fy * FR + fx) * PIXB + slot * 16) = pre;
+}
+template <int LO>
+__device__ __forceinline__ void act_store(char* buf, const uint4& pre0, const uint4& pre1, int tid) {
+  tid = opaque(tid);
+  act_store_one<LO>(buf, pre0, tid);
+  if (ActRegion<LO>::ITERS > 1) act_store_one<LO>(buf, pre1, tid + BWD_THREADS);
 }
 
 struct BwdLds { char* wts; char* bufG0; char* bufG1; char* bufAct; float* stash_gw; float* stash_x0; float* stash_dz6; const float* w_in; const float* w_out; };
@@ -578,16 +633,15 @@ __device__ __forceinline__ void s0_pixel(const ComposeBwdP& p, const BwdLds& m, 
   for (int c = 0; c < 3; ++c) dwv += g3[c] * (s3[c] - low[c]);
   // d wl: through the sigmoid and the ReLU of the last 1x1 layer (relu'(0) = 0); rounded where the layer-wise path stores it
   const float dz6 = Elem<T>::to_f32(Elem<T>::from_f32(wlv > 0.f ? dwv * w * (1.f - w) : 0.f));
-  uint4 o[3];
+  uint32_t ow[12];          // (plain words, no pointer into a struct array: that form lived in scratch memory, 48 bytes per lane)
 #pragma unroll
   for (int n4 = 0; n4 < 6; ++n4) {
     const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(m.w_out + n4 * 4);
-    uint32_t* ow = reinterpret_cast<uint32_t*>(&o[n4 >> 1]) + (n4 & 1) * 2;
-    ow[0] = pack2<T>(wv[0] * dz6, wv[1] * dz6);
-    ow[1] = pack2<T>(wv[2] * dz6, wv[3] * dz6);
+    ow[2 * n4] = pack2<T>(wv[0] * dz6, wv[1] * dz6);
+    ow[2 * n4 + 1] = pack2<T>(wv[2] * dz6, wv[3] * dz6);
   }
   uint4* dst = reinterpret_cast<uint4*>(m.bufG0 + idx * PIXB);
-  dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+  dst[0] = uint4{ow[0], ow[1], ow[2], ow[3]}; dst[1] = uint4{ow[4], ow[5], ow[6], ow[7]}; dst[2] = uint4{ow[8], ow[9], ow[10], ow[11]};
   if (fy >= 4 && fy < 20 && fx >= 4 && fx < 20) {
     const int pi = (fy - 4) * 16 + (fx - 4);
     *reinterpret_cast<float4*>(m.stash_gw + pi * 4) = make_float4(g3[0], g3[1], g3[2], w);
@@ -601,92 +655,100 @@ __device__ __forceinline__ void s0_pixel(const ComposeBwdP& p, const BwdLds& m, 
   }
 }
 
-// One role's whole tile loop.  WROLE = false: data-gradient waves 0-3 (+ the per-pixel tail S5); WROLE = true: weight-gradient waves 4-7,
-// whose 36 accumulator tiles (4 layers x 9 taps) live in registers until the end of the launch.  Both roles run the same barrier sequence.
-// acc1 / acc6: the two 1x1 layers' weight gradients of threads 0..191 (channel tid % 24, interior rows tid / 24 and + 8), reduced by the caller.
+// One role's whole tile loop.  WROLE = false: the data-gradient waves (+ S0 and the per-pixel tail S5); WROLE = true: the weight-gradient waves,
+// whose accumulator tiles (4 layers x WG_NT taps x WG_NJ output-channel tiles) live in registers until the end of the launch.  Both roles run
+// the same barrier sequence.  acc1 / acc6: the two 1x1 layers' weight gradients of the 384 threads W1_FIRST .. W1_FIRST + 383 (channel % 24,
+// interior row / 24), reduced by the caller.
 template <typename T, bool WROLE>
 __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, const int (&koff)[NCHUNK], float (&acc1)[7], float& acc6, float& accb6) {
-  const int tid = threadIdx.x, lane = tid & 63, w8 = (tid >> 6) & 7, li = lane & 15, q = lane >> 4;
-  const int mi = w8 & 1, nj = (w8 >> 1) & 1, tg = w8 >> 2;
-  f32x4_t wacc[WROLE ? 4 : 1][5];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, q = lane >> 4;
+  const int w8 = __builtin_amdgcn_readfirstlane((tid >> 6) - (WROLE ? DG_WAVES : 0));      // wave index inside the role
+#if CB_WAVES == 16
+  const int mi = w8 & 1, nj = (w8 >> 1) & 1, tap0 = (w8 >> 2) * 5;
+#else
+  const int mi = w8 & 1, nj = 0, tap0 = (w8 >> 1) * 3;
+#endif
+  constexpr int NACC = WG_NT * WG_NJ;
+  f32x4_t wacc[WROLE ? 4 : 1][NACC];
   if (WROLE) {
 #pragma unroll
     for (int l = 0; l < 4; ++l)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) wacc[l][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NACC; ++i) wacc[l][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
   const int per_img = p.tiles_y * p.tiles_x;
   const int H = p.H, W = p.W, h2 = H >> 1, w2 = W >> 1;
-  CPH_DECL(WROLE ? 512 : 0);
+  CPH_DECL(WROLE ? DG_THREADS : 0);
   constexpr int PB = WROLE ? 40 : 16;      // slots of this role's stamps
   for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
     CPH(PB + 0);
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / p.tiles_x;
     const int y0 = ty * 16, x0 = (rem - ty * p.tiles_x) * 16;
-    uint4 pre[2];
-    act_load<1>(pre, p.act[3], p.ld_act[3], b, y0, x0, H, W, tid);          // relu(r3), needed from S1 on
+    uint4 pre0, pre1 = {0u, 0u, 0u, 0u};
+    act_load<1>(pre0, pre1, p.act[3], p.ld_act[3], b, y0, x0, H, W, tid);          // relu(r3), needed from S1 on
     // ---------------------------------------------------------------- S0: blend + sigmoid + 1x1 backward on the whole frame
 #ifndef CB_EXP_NO_S0
     if (!WROLE) {                                           // (the weight-gradient role's registers are taken by its accumulators)
-      s0_pixel<T>(p, m, tid, b, y0, x0);
-      if (tid < FR * FR - 512) s0_pixel<T>(p, m, tid + 512, b, y0, x0);
+      s0_pixel<T>(p, m, opaque(tid), b, y0, x0);
+      if (tid < FR * FR - DG_THREADS) s0_pixel<T>(p, m, opaque(tid) + DG_THREADS, b, y0, x0);
     }
     CPH(PB + 1);
 #endif
-    act_store<1>(m.bufAct, pre, tid);
+    act_store<1>(m.bufAct, pre0, pre1, tid);
     CPH(PB + 2);
     __syncthreads();
     CPH(PB + 3);
     // ---------------------------------------------------------------- S1: layer 4 (input relu(r3), output gradient dA)
-    act_load<2>(pre, p.act[2], p.ld_act[2], b, y0, x0, H, W, tid);          // a2 for S2
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[WROLE ? 3 : 0], m.bufAct, m.bufG0, mi, nj, tg, lane)); }
+    act_load<2>(pre0, pre1, p.act[2], p.ld_act[2], b, y0, x0, H, W, tid);          // a2 for S2
+    if (WROLE) { CB_WGRAD((wgrad_stage<T, false, WG_NT, WG_NJ>(wacc[WROLE ? 3 : 0], m.bufAct, m.bufG0, mi, nj, tap0, lane))); }
     else { CB_DGRAD(dgrad_layer<T, 1, 0>(m.bufG0, m.bufG1, nullptr, m.bufAct, m.wts + 3 * WL_BYTES, koff, w8, li, q)); }
     CPH(PB + 4);
     __syncthreads();
     CPH(PB + 5);
-    act_store<2>(m.bufAct, pre, tid);
+    act_store<2>(m.bufAct, pre0, pre1, tid);
     CPH(PB + 6);
     __syncthreads();
     CPH(PB + 7);
     // ---------------------------------------------------------------- S2: layer 3 (input relu(a2), output gradient dc3)
-    act_load<3>(pre, p.act[1], p.ld_act[1], b, y0, x0, H, W, tid);          // relu(r1) for S3
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, true>(wacc[WROLE ? 2 : 0], m.bufAct, m.bufG1, mi, nj, tg, lane)); }
+    act_load<3>(pre0, pre1, p.act[1], p.ld_act[1], b, y0, x0, H, W, tid);          // relu(r1) for S3
+    if (WROLE) { CB_WGRAD((wgrad_stage<T, true, WG_NT, WG_NJ>(wacc[WROLE ? 2 : 0], m.bufAct, m.bufG1, mi, nj, tap0, lane))); }
     else { CB_DGRAD(dgrad_layer<T, 2, 1>(m.bufG1, m.bufG0, m.bufG0, m.bufAct, m.wts + 2 * WL_BYTES, koff, w8, li, q)); }
     CPH(PB + 8);
     __syncthreads();
     CPH(PB + 9);
-    act_store<3>(m.bufAct, pre, tid);
+    act_store<3>(m.bufAct, pre0, pre1, tid);
     CPH(PB + 10);
     __syncthreads();
     CPH(PB + 11);
     // ---------------------------------------------------------------- S3: layer 2 (input relu(r1), output gradient d a2)
-    act_load<3>(pre, p.act[0], p.ld_act[0], b, y0, x0, H, W, tid);          // a1 for S4
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[WROLE ? 1 : 0], m.bufAct, m.bufG0, mi, nj, tg, lane)); }
+    act_load<3>(pre0, pre1, p.act[0], p.ld_act[0], b, y0, x0, H, W, tid);          // a1 for S4
+    if (WROLE) { CB_WGRAD((wgrad_stage<T, false, WG_NT, WG_NJ>(wacc[WROLE ? 1 : 0], m.bufAct, m.bufG0, mi, nj, tap0, lane))); }
     else { CB_DGRAD(dgrad_layer<T, 3, 0>(m.bufG0, m.bufG1, nullptr, m.bufAct, m.wts + WL_BYTES, koff, w8, li, q)); }
     CPH(PB + 12);
     __syncthreads();
     CPH(PB + 13);
-    act_store<3>(m.bufAct, pre, tid);
+    act_store<3>(m.bufAct, pre0, pre1, tid);
     CPH(PB + 14);
     __syncthreads();
     CPH(PB + 15);
     // ---------------------------------------------------------------- S4: layer 1 (input a1, output gradient dc1) -> dz1 on the interior
-    act_load<4>(pre, p.act[4], p.ld_act[4], b, y0, x0, H, W, tid);          // a3 (interior only) for the last 1x1 layer's weight gradient
-    if (WROLE) { CB_WGRAD(wgrad_stage<T, false>(wacc[0], m.bufAct, m.bufG1, mi, nj, tg, lane)); }
+    act_load<4>(pre0, pre1, p.act[4], p.ld_act[4], b, y0, x0, H, W, tid);          // a3 (interior only) for the last 1x1 layer's weight gradient
+    if (WROLE) { CB_WGRAD((wgrad_stage<T, false, WG_NT, WG_NJ>(wacc[0], m.bufAct, m.bufG1, mi, nj, tap0, lane))); }
     else { CB_DGRAD(dgrad_layer<T, 4, 2>(m.bufG1, m.bufG0, m.bufG0, m.bufAct, m.wts, koff, w8, li, q)); }
     CPH(PB + 16);
     __syncthreads();
     CPH(PB + 17);
 
     // ---------------------------------------------------------------- S5: first 1x1 layer + blend: d fine, d small, dW1, dW6
-    act_store<4>(m.bufAct, pre, tid);
+    act_store<4>(m.bufAct, pre0, pre1, tid);
     __syncthreads();                                          // a3 has landed in the activation buffer; the two parts of S5 run side by side
     CPH(PB + 18);
 #ifndef CB_EXP_NO_S5
-    const int n24 = (tid - 256) % 24, row0 = (tid - 256) / 24;      // threads 256..639: channel n24, interior row row0 (0..15)
+    const int t5 = opaque(tid);
+    const int n24 = (t5 - W1_FIRST) % 24, row0 = (t5 - W1_FIRST) / 24;      // threads W1_FIRST .. +383: channel n24, interior row row0 (0..15)
     if (!WROLE && tid < 256) {                                // threads 0..255: one interior pixel each
-      const int bq = tid >> 2, sub = tid & 3;                 // a 2x2 block = 4 consecutive lanes
+      const int bq = t5 >> 2, sub = t5 & 3;                   // a 2x2 block = 4 consecutive lanes
       const int y = 2 * (bq >> 3) + (sub >> 1), x = 2 * (bq & 7) + (sub & 1);
       const int pi = y * 16 + x;
       const T* zp = reinterpret_cast<const T*>(m.bufG0 + ((4 + y) * FR + 4 + x) * PIXB);
@@ -724,7 +786,7 @@ __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, 
         }
       }
     }
-    if (tid >= 256 && tid < 640) {                            // the two 1x1 layers' weight gradients, one (channel, interior row) per thread
+    if (tid >= W1_FIRST && tid < W1_FIRST + 384) {            // the two 1x1 layers' weight gradients, one (channel, interior row) per thread
       const char* zrow = m.bufG0 + ((4 + row0) * FR + 4) * PIXB;
       const char* arow = m.bufAct + ((4 + row0) * FR + 4) * PIXB;
 #pragma unroll 4
@@ -747,21 +809,22 @@ __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, 
   }
 
   if (WROLE) {            // flush: one atomic per weight-gradient element per workgroup
-    const int co = nj * 16 + li;
 #pragma unroll
     for (int l = 0; l < 4; ++l)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int tap = tg * 5 + i;
-        if (co >= 24 || tap > 8) continue;
+      for (int i = 0; i < WG_NT; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ci = mi * 16 + q * 4 + e;
-          const float v = wacc[WROLE ? l : 0][i][e];
-          if (ci < 24) atomicAdd(p.dw_res[l] + (tap * 24 + ci) * 24 + co, v);
-          else if (ci == 24 && tap == 4) atomicAdd(p.db_res[l] + co, v);
+        for (int j = 0; j < WG_NJ; ++j) {
+          const int tap = tap0 + i, co = (nj + j) * 16 + li;
+          if (co >= 24 || tap > 8) continue;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ci = mi * 16 + q * 4 + e;
+            const float v = wacc[WROLE ? l : 0][i * WG_NJ + j][e];
+            if (ci < 24) atomicAdd(p.dw_res[l] + (tap * 24 + ci) * 24 + co, v);
+            else if (ci == 24 && tap == 4) atomicAdd(p.db_res[l] + co, v);
+          }
         }
-      }
   }
 }
 
@@ -804,16 +867,16 @@ __global__ __launch_bounds__(BWD_THREADS) void compose_bwd_kernel(const ComposeB
   float acc1[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc6 = 0.f, accb6 = 0.f;
   // Nothing role-specific lives across the role branch: the weight-gradient role keeps 144 accumulator registers for the whole launch,
   // the data-gradient role its 56 weight-fragment registers per layer -- together they would not fit a wave's 256.
-  if (wave < 8) bwd_role<T, false>(p, m, koff, acc1, acc6, accb6);
+  if (wave < DG_WAVES) bwd_role<T, false>(p, m, koff, acc1, acc6, accb6);
   else bwd_role<T, true>(p, m, koff, acc1, acc6, accb6);
 
   float* red = reinterpret_cast<float*>(smem);               // [row pair][n][9]: the weight images are no longer needed
   __syncthreads();
-  if (tid >= 256 && tid < 640) {
+  if (tid >= W1_FIRST && tid < W1_FIRST + 384) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) red[(tid - 256) * 9 + k] = acc1[k];
-    red[(tid - 256) * 9 + 7] = acc6;
-    red[(tid - 256) * 9 + 8] = accb6;
+    for (int k = 0; k < 7; ++k) red[(tid - W1_FIRST) * 9 + k] = acc1[k];
+    red[(tid - W1_FIRST) * 9 + 7] = acc6;
+    red[(tid - W1_FIRST) * 9 + 8] = accb6;
   }
   __syncthreads();
   if (tid < 24 * 9) {

@@ -62,6 +62,23 @@ from deepdenoiser_amd.naming import Naming
 from deepdenoiser_amd.render_passes import RenderPasses
 
 
+class _RoundBackwardMasked(torch.autograd.Function):
+    """y = x (a ReLU output with several consumers); this consumer's gradient contribution is masked by x > 0 and rounded to the storage
+    type before it is added to the others': every data-gradient launch of the half-precision path rounds its own result, then adds the
+    gradient already stored and rounds the sum (csrc/dd_conv_bwd.hip, dd_convt.hip, dd_head.hip epilogues)."""
+
+    @staticmethod
+    def forward(ctx, x, st):
+        ctx.st = st
+        ctx.save_for_backward(x)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return (g * (x > 0)).to(ctx.st).to(g.dtype), None
+
+
 class VarStore:
     """Ordered variable store emulating TF variable scopes with reuse + per-scope layer counters."""
 
@@ -101,6 +118,11 @@ class VarStore:
         """The point where the reverse program stores this tensor's gradient."""
         return x if self.storage is None else _RoundBackward.apply(x, self.storage)
 
+    def branch(self, x):
+        """One consumer's view of a ReLU output that has several consumers (U-Net skip tensors, backbone outputs feeding both the next
+        transposed conv and a kernel-prediction head)."""
+        return x if self.storage is None else _RoundBackwardMasked.apply(x, self.storage)
+
     def _stored(self, pre, relu):
         pre = self.qgrad(pre)                  # stored gradients are PRE-activation gradients: masked by the ReLU, then rounded
         return self.q(torch.relu(pre) if relu else pre)
@@ -137,7 +159,12 @@ class VarStore:
         bias = self.get(name + "/bias", (filters,))
         if self.storage is None:
             return T.conv2d_transpose_s2(x, kernel, bias, relu)
-        return self._stored(T.conv2d_transpose_s2(x, self.q(kernel), bias, False), relu)
+        kq = self.q(kernel)
+        if k == 2 and filters > 64:      # dd_convt2x2_bwd: one launch per 64 output channels, the later ones accumulating into dx
+            pre = torch.cat([T.conv2d_transpose_s2(self.branch(x), kq[:, :, c0:c0 + 64], bias[c0:c0 + 64], False) for c0 in range(0, filters, 64)], dim=3)
+        else:
+            pre = T.conv2d_transpose_s2(x, kq, bias, False)
+        return self._stored(pre, relu)
 
 
 # ----------------------------------------------------------------------------- backbones
@@ -154,14 +181,14 @@ def unet_predict(vs, scope, x, filters, convs_per_block, multiscale):
     for i in range(steps):
         x = block(x, filters[i])
         skips.append(x)
-        x = T.max_pool_same(x, 3, 2)                            # UNet.py:38-52
+        x = T.max_pool_same(vs.branch(x), 3, 2)                 # UNet.py:38-52
     for i in range(steps):
         index = steps - i
         x = block(x, filters[index], split_at=filters[index] if i > 0 else None)     # [skip | upsampled]: filters[index] channels each
         if multiscale:
             results.append(x)
-        x = vs.conv2d_transpose(scope, x, filters[index - 1], 2, relu=True)   # UNet.py:54-59
-        x = torch.cat([skips[index - 1], x], dim=3)             # UNet.py:91-92
+        x = vs.conv2d_transpose(scope, vs.branch(x) if multiscale else x, filters[index - 1], 2, relu=True)   # UNet.py:54-59
+        x = torch.cat([vs.branch(skips[index - 1]), x], dim=3)  # UNet.py:91-92
     x = block(x, filters[0], split_at=filters[0])
     results.append(x)
     return results
@@ -342,7 +369,9 @@ class OracleArchitecture:
                 outs = tiramisu_predict(vs, scope, x, self.filters, self.convs_per_block, self.use_multiscale)
             internals.setdefault("core_outputs", []).append(outs)
             post = []
-            for o in outs:                                            # coarsest first (:573-575)
+            for i_out, o in enumerate(outs):                          # coarsest first (:573-575)
+                if self.core_name == "U-Net" and i_out < len(outs) - 1:
+                    o = vs.branch(o)                                  # (storage emulation: this output also feeds the next transposed conv)
                 o = vs.conv2d(scope, o, self.post_channels, 1, relu=True)
                 o = vs.conv2d(scope, o, self.post_channels, 1, relu=False)
                 post.append(o)

@@ -10,10 +10,12 @@ import os
 #          1.4e-4 (fp16) -- gated at <= 2 roundings' worth so that a 1-ulp flip on a rounding boundary passes and a dropped channel, tap or
 #          halo column (>= 1/192 of the terms = 5e-3 relative at the very least) does not;
 #   ACC32  an fp32 output (dW, db, kernel-prediction output) computed from representable inputs: bf16 x bf16 products are exact in fp32, so
-#          only the fp32 summation order differs from the f64 oracle.
+#          only the fp32 summation order differs from the f64 oracle: 5e-6 (a dropped term out of ~10^4..10^6 would still show at ~1e-3).
 TOL = {"f32": 3e-5, "bf16": 2.5e-2, "f16": 3.5e-3}
-ROUND = {"f32": 3e-5, "bf16": 4e-3, "f16": 5e-4}
-ACC32 = {"f32": 3e-5, "bf16": 1e-4, "f16": 1e-4}
+# measured over the whole op suite (profiles/r03_parity_errors.txt): one rounding = 1.67e-3 (bf16) / 2.08e-4 (fp16), worst storage-type
+# output 2.5e-3 / 3.1e-4 (two roundings: a conv over a split skip concat); fp32 outputs <= 3e-7 in every storage type; f32 path <= 7e-7
+ROUND = {"f32": 5e-6, "bf16": 4e-3, "f16": 5e-4}
+ACC32 = {"f32": 5e-6, "bf16": 5e-6, "f16": 5e-6}
 
 # every comparison of the session: (test id, name, measured rel-L2, gate); tests/conftest.py writes them to gpurun_out/parity_errors.txt
 RECORDS = []

@@ -41,6 +41,7 @@ def _pair(aj, dtype, B, H, W, tj=None):
     from deepdenoiser_amd.architecture import Architecture
     oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
     feats, labels = _inputs(oracle, B, H, W)
+    feats = _with_flags(aj, feats, B, H, W)
     preds_o = oracle.predict(feats)
     arch = Architecture(aj, device="cuda", dtype=dtype)
     prog = arch.program(B, H, W, training_json=tj)
@@ -109,7 +110,7 @@ def test_forward_parity_f32(case):
 
 
 @pytest.mark.parametrize("case", ["cfg1_small_unet_direct", "example_json_single_embedding", "cfg2_unet_kpcn_real_filters", "combined_tuples_kp3",
-                                  "tiramisu_multiscale", "ragged_tile_three_scales"])
+                                  "tiramisu_multiscale", "ragged_tile_three_scales", "one_hot_no_multiscale_raw_kp_source", "invert_before_multiscale"])
 def test_training_step_parity_f32(case):
     """loss, every parameter gradient, and a 3-step Adam trajectory."""
     _need_gpu()

@@ -1,7 +1,7 @@
 """-m gpu: hand-written HIP kernels (through the C-ABI + engine) vs the CPU oracle, op by op.
 Inputs, weights and upstream gradients are REPRESENTABLE in the storage type, so every product is exact in fp32 and the gates are set by what
 an output is (tests/gpu_util.py): storage-type outputs (y, dx) within one-to-two roundings (ROUND: bf16 4e-3, fp16 5e-4), fp32 outputs
-(dW, db, kernel-prediction output) within fp32 summation order (ACC32: 1e-4 for bf16 and fp16 alike), the f32 path 3e-5 throughout."""
+(dW, db, kernel-prediction output) within fp32 summation order (ACC32: 5e-6 for bf16 and fp16 alike), the f32 path 5e-6 throughout."""
 import ctypes
 
 import numpy as np
@@ -220,7 +220,8 @@ def test_conv_grad_accumulation_and_concat_views(eng, dtype, f, H, W):
     # first writer rounds, second writer reads that, adds and rounds again (the oracle rounds the f64 sum once): <= 2 roundings
     check("dx(accumulated)", read(x.grad()), grads[0] * (xv > 0), 2 * ROUND[dtype])
     for lay, gw in zip((l1, l2, l3), grads[1:]):
-        check("dW " + lay.name, g.params.grad(lay.kernel).double().cpu(), gw, 3 * ACC32[dtype])
+        # (half precision: a stored gradient that lands on the other side of a rounding boundary than the f64 chain's moves dW by ~1e-5)
+        check("dW " + lay.name, g.params.grad(lay.kernel).double().cpu(), gw, ACC32[dtype] if dtype == "f32" else 1e-4)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -334,7 +335,7 @@ def test_kernel_prediction_apply(lib, eng, dtype, ks):
     so = src[..., :3].double().cpu()
     lo = lg[..., :k2].clone().requires_grad_(True)
     oo = T.kernel_prediction(so, lo, ks)
-    check("kp out", out.cpu(), oo.detach(), 2e-5)
+    check("kp out", out.cpu(), oo.detach(), ACC32[dtype])
     G = torch.randn(B, H, W, 3, generator=gen)
     (gl,) = torch.autograd.grad((oo * G.double()).sum(), [lo])
     dl = torch.full((B, H, W, ld), 7.0, dtype=tdt).cuda()

@@ -38,11 +38,16 @@ def _train(case, force_collectives, use_graph):
     trainer = Trainer(arch, tj, GLOBAL_B, H, W, world_size=1, use_graph=use_graph, n_buckets=3, force_segments=True, force_collectives=force_collectives)
     feats, labels = _global_batch(arch)
     trainer.program.set_inputs({k: v.cuda() for k, v in feats.items()}, {k: v.cuda() for k, v in labels.items()})
-    losses = [float(trainer.step()) for _ in range(STEPS)]
+    losses, grads1 = [], None
+    for step in range(STEPS):
+        losses.append(float(trainer.step()))
+        if step == 0:
+            torch.cuda.synchronize()
+            grads1 = arch.params.grads.cpu().clone()       # what the optimizer consumed at step 1 (all-reduced over the one rank)
     torch.cuda.synchronize()
     assert len(trainer._segments) == 3 and (trainer._graphs is not None) == use_graph
     assert trainer.reducer.active == force_collectives
-    return {"losses": losses, "values": arch.params.values.cpu().clone(), "grads": arch.params.grads.cpu().clone(), "mask_sums": trainer.program.mask_sums.cpu().clone()}
+    return {"losses": losses, "values": arch.params.values.cpu().clone(), "grads1": grads1, "mask_sums": trainer.program.mask_sums.cpu().clone()}
 
 
 def _worker(rank, port, case, out):
@@ -83,7 +88,7 @@ def test_one_rank_rccl_trainer_matches_the_plain_step(case, tmp_path):
         tol = 2e-6 if s == 0 else 2e-4
         assert abs(r["losses"][s] - plain["losses"][s]) <= tol * abs(plain["losses"][s]), (s, r["losses"][s], plain["losses"][s])
     assert torch.equal(r["mask_sums"], plain["mask_sums"])
-    assert rel_l2(r["grads"], plain["grads"]) < 2e-3          # step-4 gradients of two runs whose weights differ by atomics' rounding
+    assert rel_l2(r["grads1"], plain["grads1"]) < 2e-5        # step-1 gradients: equal up to the fp32 atomics' summation order
     d = (r["values"] - plain["values"]).abs()
     assert float(d.max()) <= 2 * STEPS * lr
     assert float((d > 0.5 * lr).float().mean()) < 0.02

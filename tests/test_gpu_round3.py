@@ -36,7 +36,8 @@ def _emulated_step(aj, tj, dtype, feats, labels, loss_scale):
     return oracle, [{k: v.detach() for k, v in d.items()} for d in preds], float(loss), grads
 
 
-def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate):
+def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate, fwd_median_gate=None, tight=None):
+    """tight = (name prefixes, gate): parameters whose gradient must match at summation-order level (see the bit-faithful test below)."""
     from deepdenoiser_amd.architecture import Architecture
     plain = OracleArchitecture(aj, dtype=torch.float64, seed=2)
     feats, labels = _inputs(plain, B, H, W)
@@ -50,11 +51,14 @@ def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate
     loss = float(prog.train_step(dev, devl))
     torch.cuda.synchronize()
     preds = prog.prediction_dictionaries()
-    worst = 0.0
+    fwd = []
     for s, (dp, do) in enumerate(zip(preds, preds_o)):
         for k in do:
             assert torch.isfinite(dp[k]).all()
-            worst = max(worst, check("%s %s scale %d %s" % (what, dtype, s, k), dp[k].cpu(), do[k], fwd_gate))
+            fwd.append(check("%s %s scale %d %s" % (what, dtype, s, k), dp[k].cpu(), do[k], fwd_gate))
+    fwd.sort()
+    if fwd_median_gate is not None:
+        gate("%s %s forward median over %d predictions" % (what, dtype, len(fwd)), fwd[len(fwd) // 2], fwd_median_gate)
     gate("%s %s loss rel err" % (what, dtype), abs(loss - loss_o) / abs(loss_o), loss_gate)
     errs = []
     for p, go in zip(arch.params.params, grads_o):
@@ -62,19 +66,31 @@ def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate
         if float(go.norm()) == 0.0:
             assert float(got.abs().max()) < 1e-6, p.name
             continue
-        errs.append((rel_l2(got, go), p.name))
-    errs.sort()
-    med, (mx, mx_name) = errs[len(errs) // 2][0], errs[-1]
-    print("%s, %s storage vs the storage-emulating oracle: forward worst rel-L2 %.3e, loss rel err %.2e, gradient rel-L2 median %.3e max %.3e (%s) over %d tensors"
-          % (what, dtype, worst, abs(loss - loss_o) / abs(loss_o), med, mx, mx_name, len(errs)))
-    gate("%s %s gradient median" % (what, dtype), med, grad_median_gate)
-    gate("%s %s gradient max (%s)" % (what, dtype, mx_name), mx, grad_max_gate)
+        e = rel_l2(got, go)
+        errs.append((e, p.name))
+        if tight is not None and any(p.name.startswith(pre) for pre in tight[0]):
+            gate("%s %s gradient %s" % (what, dtype, p.name), e, tight[1])
+    by_err = sorted(errs)
+    med, (mx, mx_name) = by_err[len(by_err) // 2][0], by_err[-1]
+    print("%s, %s storage vs the storage-emulating oracle: forward median %.2e worst %.2e, loss rel err %.2e, gradient rel-L2 median %.2e max %.2e (%s) over %d tensors"
+          % (what, dtype, fwd[len(fwd) // 2], fwd[-1], abs(loss - loss_o) / abs(loss_o), med, mx, mx_name, len(errs)))
+    if grad_median_gate is not None:
+        gate("%s %s gradient median" % (what, dtype), med, grad_median_gate)
+        gate("%s %s gradient max (%s)" % (what, dtype, mx_name), mx, grad_max_gate)
     assert torch.isfinite(arch.params.grads).all()
     return errs
 
 
-# measured (profiles/r03_parity_errors.txt); each gate ~2x the measured value
-FULL_SIZE_GATES = {"bf16": (2e-3, 5e-4, 4e-3, 2e-2), "f16": (3e-4, 1e-4, 6e-4, 4e-3)}
+# What the emulation can and cannot certify (measured, profiles/r03_parity_errors.txt and tools/emu_debug.py):
+#   * a half-precision network is CHAOTIC in its rounding decisions: a value that lands on the other side of a rounding boundary than the f64
+#     chain's (fp32 vs f64 summation, probability ~1e-4 per element) perturbs 9 x C_out x |w| >> 1 elements of the next layer by up to an ulp
+#     each, so one flip decorrelates everything downstream within a few layers -- the comparison is all-or-nothing.  Small networks: most
+#     predictions agree to 1e-7 (the fused head / compose / conv kernels are bit-faithful to "round once where the tensor is stored"), the few
+#     hit by a flip sit at one-to-two roundings.  Full size: every prediction carries flips (5.5e-3 bf16, 7e-4 fp16) and per-tensor gradients
+#     are no closer to the emulation than to the plain oracle (their sums cancel heavily, which amplifies rounding-level differences).
+#   * so: forward gates at 3 roundings (max) and 1e-5 (median, small bf16 networks); gradient gates at the storage type's own error here, at
+#     summation-order level in test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful below, and per op in tests/test_gpu_ops.py.
+FULL_SIZE_GATES = {"bf16": (1.2e-2, 5e-4, 0.045, 0.16), "f16": (1.5e-3, 1e-4, 0.016, 0.055)}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -86,7 +102,7 @@ def test_cfg2_full_size_half_precision_against_the_storage_emulating_oracle(dtyp
     _compare("cfg-2 128x128 B=2", dtype, aj, tj, 2, 128, 128, *FULL_SIZE_GATES[dtype])
 
 
-SMALL_GATES = {"bf16": (4e-3, 1e-3, 1e-2, 5e-2), "f16": (5e-4, 2e-4, 2e-3, 1e-2)}
+SMALL_GATES = {"bf16": (1.5e-2, 1e-3, 0.1, 0.6), "f16": (4e-3, 2e-4, 0.1, 0.6)}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -99,7 +115,46 @@ def test_small_networks_half_precision_against_the_storage_emulating_oracle(case
     aj, B, H, W = CASES[case]
     single_feature = len(aj["combined_features"]) == 1
     tj = configs.bench_training() if single_feature else configs.training()
-    _compare(case, dtype, aj, tj, B, H, W, *SMALL_GATES[dtype])
+    fwd_gate, loss_gate, gmed, gmax = SMALL_GATES[dtype]
+    if case == "one_hot_no_multiscale_raw_kp_source":
+        # kernel prediction on the RAW source + expm1 inversion: predictions reach exp(46) here, where the SMAPE gradient (2t + eps) / (p + t + eps)^2
+        # cancels catastrophically in fp32 (device and TensorFlow alike; measured 1e-2 against f64 on the f32 path too): forward and loss only
+        gmed = gmax = None
+    # bf16 networks with many tuples: the majority of the predictions must be bit-faithful (fp16: subnormal handling differs from torch's)
+    many = dtype == "bf16" and case in ("example_json_single_embedding", "ragged_tile_three_scales", "combined_tuples_kp3", "invert_before_multiscale")
+    _compare(case, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, gmed, gmax, fwd_median_gate=1e-5 if many else None)
+
+
+BIT_FAITHFUL = {
+    # one feature tuple, so that no other tuple's rounding flips leak into the shared weights' gradients
+    "k5_two_scales": (configs.architecture(filters=(16, 16), convs=1, invert_after_multiscale=False, flag_mode="NONE",
+                                           combined={"Emission": {"Color": "Emission", "Direct": "", "Indirect": ""}}), 2, 32, 16),
+    "k3_two_scales": (configs.architecture(filters=(16, 16), convs=1, kernel_size=3, flag_mode="NONE",
+                                           combined={"Emission": {"Color": "Emission", "Direct": "", "Indirect": ""}}), 2, 16, 32),
+    "k5_three_scales_ragged": (configs.architecture(filters=(16, 16, 24), convs=1, flag_mode="NONE",
+                                                    combined={"Emission": {"Color": "Emission", "Direct": "", "Indirect": ""}}), 1, 24, 40),
+}
+
+
+@pytest.mark.parametrize("case", list(BIT_FAITHFUL))
+def test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful(case):
+    """bf16, tiny single-tuple networks whose forward is bit-faithful to the emulation: the gradients the reverse program computes FIRST -- the
+    compose net's six layers (csrc/dd_compose.hip backward, 12 waves) and the 1x1 head layers of every scale (csrc/dd_head.hip backward) -- must
+    agree with the storage-emulating oracle at summation-order level (measured 3e-8 ... 5e-6), two to three orders of magnitude below one
+    bf16 rounding.  Further upstream the comparison decays through rounding flips (see above) and is only sanity-gated.
+    If this fails after a change that reorders an fp32 summation, look at the forward first: a single new flip there explains it."""
+    _need_gpu()
+    aj, B, H, W = BIT_FAITHFUL[case]
+    tj = configs.bench_training()
+    n_scales = len(aj["architecture"]["core_architecture"]["number_of_filters_for_convolution_blocks"])
+    n_core = 2 * n_scales * 1 + (n_scales - 1) + 1            # convs of the U-Net (1 per block) + transposed convs: conv2d .. conv2d_{n_core-...}
+    # head layers = the last 2 * n_scales conv2d of the core scope
+    oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
+    oracle.predict(_inputs(oracle, B, H, W)[0])
+    core_convs = [n for n in oracle.vs.vars if n.startswith("reused_core_architecture/conv2d") and "transpose" not in n and n.endswith("/kernel")]
+    head = [n[:-len("kernel")] for n in core_convs[-2 * n_scales:]]
+    errs = _compare("bit-faithful " + case, "bf16", aj, tj, B, H, W, 1e-5, 1e-4, 0.1, 0.6, tight=(["reused_compose_scales/"] + head, 1e-4))
+    assert len(errs) > 10
 
 
 @pytest.mark.parametrize("dtype,grad_median_gate,grad_max_gate", [("bf16", 0.045, 0.16), ("f16", 0.016, 0.055)])
