@@ -23,16 +23,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # recogniser sees inside the asm) are only CORRECT while hipcc neither spills nor otherwise touches those registers.  (2) The fused head /
 # compose / register-weight / transposed-conv kernels are HBM- or latency-bound: a spill there is silent HBM traffic (round 2 shipped a
 # compose backward that wrote 15x its algorithmic bytes to scratch).  A build in which one of them reports a non-zero ScratchSize is refused.
-NO_SCRATCH_TARGET = {
+NO_SCRATCH = {
     "dd_conv_bwd.hip": ("conv_bwd_kernel",),
     "dd_convt.hip": ("convt_bwd_kernel", "convt_fwd_kernel"),
     "dd_conv_rw.hip": ("conv_rw_kernel", "conv_rw8_kernel"),
     "dd_compose.hip": ("compose_fwd_kernel", "compose_bwd_kernel"),
     "dd_head.hip": ("head_fwd_kernel", "head_bwd_kernel"),
 }
-
-
-NO_SCRATCH = {"dd_conv_bwd.hip": ("conv_bwd_kernel",), "dd_convt.hip": ("convt_bwd_kernel",)}   # TEMP while the spills are being fixed
 
 
 def source_hash():

@@ -194,15 +194,14 @@ __device__ __forceinline__ void load_x(uint4 (&xf)[NCH], const HeadP& a, long pi
 // a1_lds != nullptr: the GEMM-1 weight fragments are read from a fragment-ready LDS image ([j][c][lane] x 16 bytes) instead of registers
 // (the backward kernel keeps up to 22 gradient tiles in registers and has none to spare for them)
 template <typename T, int KS, int NCH>
-__device__ __forceinline__ void forward_gemms(const FwdWeights<T, KS, NCH>& w, const uint4 (&xf)[NCH], uint4& hid, float (&lg)[HeadDim<KS>::NT][4],
-                                              const uint4* a1_lds = nullptr) {
+__device__ __forceinline__ void forward_gemms(const FwdWeights<T, KS, NCH>& w, const uint4 (&xf)[NCH], uint4& hid, float (&lg)[HeadDim<KS>::NT][4]) {
   constexpr int NT = HeadDim<KS>::NT;
   float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     f32x4_t acc = {w.b1[j][0], w.b1[j][1], w.b1[j][2], w.b1[j][3]};
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) acc = mma16<T>(a1_lds ? a1_lds[(j * NCH + c) * 64] : w.a1[j][c], xf[c], acc);
+    for (int c = 0; c < NCH; ++c) acc = mma16<T>(w.a1[j][c], xf[c], acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) h[j * 4 + e] = fmaxf(acc[e], 0.f);
   }
@@ -211,6 +210,30 @@ __device__ __forceinline__ void forward_gemms(const FwdWeights<T, KS, NCH>& w, c
   for (int j = 0; j < NT; ++j) {
     f32x4_t acc = {w.b2[j][0], w.b2[j][1], w.b2[j][2], w.b2[j][3]};
     acc = mma16<T>(w.a2[j], hid, acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lg[j][e] = Elem<T>::to_f32(Elem<T>::from_f32(acc[e]));
+  }
+}
+
+// The same two GEMMs with every lane-dependent operand read from the workgroup's fragment image in LDS (backward kernel: its registers go to the
+// weight-gradient tiles): image = [a1: NT * NCH][a4: 2 NCH][a3: NT][a2: NT][b1: NT][b2: NT] x 64 lanes x 16 bytes, `img` already offset by the lane.
+template <typename T, int KS, int NCH>
+__device__ __forceinline__ void forward_gemms_lds(const uint4* img, const uint4 (&xf)[NCH], uint4& hid, float (&lg)[HeadDim<KS>::NT][4]) {
+  constexpr int NT = HeadDim<KS>::NT, A2 = NT * NCH + 2 * NCH + NT, B1 = A2 + NT, B2 = B1 + NT;
+  float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    f32x4_t acc = *reinterpret_cast<const f32x4_t*>(img + (B1 + j) * 64);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc = mma16<T>(img[(j * NCH + c) * 64], xf[c], acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[j * 4 + e] = fmaxf(acc[e], 0.f);
+  }
+  hid = pack8t<T>(h);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    f32x4_t acc = *reinterpret_cast<const f32x4_t*>(img + (B2 + j) * 64);
+    acc = mma16<T>(img[(A2 + j) * 64], hid, acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) lg[j][e] = Elem<T>::to_f32(Elem<T>::from_f32(acc[e]));
   }
@@ -249,7 +272,8 @@ template <typename T, int KS, int NCH>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadP a) {
   constexpr int NT = HeadDim<KS>::NT;
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  // (readfirstlane: the wave index is uniform, so the segment walk -- image, row, x-segment, segments left -- lives in scalar registers)
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   __shared__ float s_w[128 * HeadDim<KS>::K + HeadDim<KS>::K * HeadDim<KS>::K + 2 * HeadDim<KS>::K];
   const HeadW hw = stage_head_weights<KS>(s_w, a, 256);
   FwdWeights<T, KS, NCH> w;
@@ -301,14 +325,16 @@ __device__ __forceinline__ uint4 strip_frag_tr(const char* strip, int row_bytes,
 }
 
 constexpr int BWD_WAVES = 8;      // one persistent workgroup per CU, 2 waves per SIMD (a wave's 32-pixel step is a chain of memory round trips)
-template <typename T, int KS, int NCH>
+// ACCUM (d x is added to a gradient already stored) is a template flag: as a runtime branch the never-taken side still cost the 2 * NCH * 2
+// registers of the old gradient, and the 128-channel instantiation spilled 55 registers (round 2).
+template <typename T, int KS, int NCH, bool ACCUM>
 __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a) {
   constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, P = HeadDim<KS>::P, ONES = HeadDim<KS>::ONES_POS;
   constexpr int CT = NCH * 2;                          // 16-channel tiles of x
   constexpr int XROW = NCH * 64, STRIP = 32 * (3 * 64 + XROW);
-  constexpr int NA1 = HeadDim<KS>::NT * NCH;           // fragment-ready weight images behind the strips: GEMM 1 (NA1 KiB) and GEMM 4 (CT KiB)
+  constexpr int NA1 = HeadDim<KS>::NT * NCH;           // fragment-ready operand image behind the strips (forward_gemms_lds): a1, a4, a3, a2, b1, b2
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* s_hid = smem + wv * STRIP;                     // [32 px][32 slots] hid (slot order, position ONES := 1)
   char* s_dl = s_hid + 32 * 64;                        // [32 px][32 slots] d logits
   char* s_dh = s_dl + 32 * 64;                         // [32 px][32 slots] d hid (pre-activation)
@@ -352,6 +378,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
   }
   uint4* s_a1 = reinterpret_cast<uint4*>(smem + BWD_WAVES * STRIP) + lane;
   uint4* s_a4 = s_a1 + NA1 * 64;
+  uint4* s_a3 = s_a4 + CT * 64;
   if (wv == 0) {                                       // the fragments depend on the lane only: one wave publishes them for all
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -359,6 +386,13 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
       for (int c = 0; c < NCH; ++c) s_a1[(j * NCH + c) * 64] = w.a1[j][c];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) s_a4[ct * 64] = a4[ct];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s_a3[j * 64] = a3[j];
+      s_a3[(NT + j) * 64] = w.a2[j];
+      *reinterpret_cast<f32x4_t*>(s_a3 + (2 * NT + j) * 64) = f32x4_t{w.b1[j][0], w.b1[j][1], w.b1[j][2], w.b1[j][3]};
+      *reinterpret_cast<f32x4_t*>(s_a3 + (3 * NT + j) * 64) = f32x4_t{w.b2[j][0], w.b2[j][1], w.b2[j][2], w.b2[j][3]};
+    }
   }
   __syncthreads();                                     // every wave has its fragments: the staged weights give way to the strips
   HPH(2);
@@ -427,31 +461,36 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
 #endif
       T* dxp = reinterpret_cast<T*>(a.dx) + (long)pix * a.lddx;
       const T* xp = reinterpret_cast<const T*>(a.x) + (long)pix * a.ldx;
-      uint2 xm[CT], old[CT];
+      uint2 xm[CT], old[ACCUM ? CT : 1];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int c = ct * 16 + q * 4, cc = c < a.C ? c : 0;
 #ifdef HB_EXP_NO_DX
-        xm[ct] = uint2{(unsigned)cc, 0u}; old[ct] = uint2{0u, 0u};
+        xm[ct] = uint2{(unsigned)cc, 0u};
+        if (ACCUM) old[ACCUM ? ct : 0] = uint2{0u, 0u};
 #else
         xm[ct] = *reinterpret_cast<const uint2*>(xp + cc);
-        old[ct] = a.accumulate ? *reinterpret_cast<const uint2*>(dxp + cc) : uint2{0u, 0u};
+        if (ACCUM) old[ACCUM ? ct : 0] = *reinterpret_cast<const uint2*>(dxp + cc);
 #endif
       }
 
-      uint4 hid;
-      float p[NT][4];
-      forward_gemms<T, KS, NCH>(w, xf, hid, p, s_a1);
-      softmax4<KS>(p, q);
-      // d logits of this lane's channels: p_t (dp_t - sum_u p_u dp_u),  dp_t = d out . src[tap t]
-      float dp[NT][4], dot = 0.f;
+      // dp_t = d out . src[tap t] of this lane's taps, taken as soon as the taps have arrived (they were requested first: the later mask / gradient
+      // loads stay in flight behind them) -- 8 live registers through the GEMMs below instead of the 24 of the source values
+      float dp[NT][4];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dp[j][e] = g0 * sv[j][e][0] + g1 * sv[j][e][1] + g2 * sv[j][e][2];
-          dot += p[j][e] * dp[j][e];
-        }
+        for (int e = 0; e < 4; ++e) dp[j][e] = g0 * sv[j][e][0] + g1 * sv[j][e][1] + g2 * sv[j][e][2];
+      uint4 hid;
+      float p[NT][4];
+      forward_gemms_lds<T, KS, NCH>(s_a1, xf, hid, p);
+      softmax4<KS>(p, q);
+      // d logits of this lane's channels: p_t (dp_t - sum_u p_u dp_u)
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dot += p[j][e] * dp[j][e];
       dot += __shfl_xor(dot, 16);
       dot += __shfl_xor(dot, 32);
       float dlv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -467,7 +506,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma16<T>(a3[j], dl, acc);
+        acc = mma16<T>(s_a3[j * 64], dl, acc);
 #pragma unroll
         for (int e = 0; e < 4; ++e) dhv[j * 4 + e] = acc[e];
       }
@@ -481,10 +520,10 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
         uint2 o2;
         o2.x = mask_bf16x2(pack2<T>(acc[0], acc[1]), xm[ct].x);
         o2.y = mask_bf16x2(pack2<T>(acc[2], acc[3]), xm[ct].y);
-        if (a.accumulate) {
+        if (ACCUM) {
           float f8[8], g8[8];
           unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
-          unpack8t<T>(uint4{old[ct].x, old[ct].y, 0u, 0u}, g8);
+          unpack8t<T>(uint4{old[ACCUM ? ct : 0].x, old[ACCUM ? ct : 0].y, 0u, 0u}, g8);
           o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
           o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
         }
@@ -509,11 +548,16 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
         else if (OW == 2) hs.z = (hs.z & keep) | one;
         else hs.w = (hs.w & keep) | one;
       }
-      *reinterpret_cast<uint4*>(s_hid + row * 64 + q * 16) = hs;
-      *reinterpret_cast<uint4*>(s_dl + row * 64 + q * 16) = keep4(dl);
-      *reinterpret_cast<uint4*>(s_dh + row * 64 + q * 16) = keep4(dh);
+      // (one opaque base per strip: left alone hipcc keeps a lane-constant address register per store alive across the whole loop)
+      int park = row * 64 + q * 16;
+      asm volatile("" : "+v"(park));
+      *reinterpret_cast<uint4*>(s_hid + park) = hs;
+      *reinterpret_cast<uint4*>(s_hid + 32 * 64 + park) = keep4(dl);
+      *reinterpret_cast<uint4*>(s_hid + 2 * 32 * 64 + park) = keep4(dh);
+      int parkx = row * XROW + q * 16;
+      asm volatile("" : "+v"(parkx));
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(s_x + row * XROW + c * 64 + q * 16) = keep4(xf[c]);
+      for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(s_x + parkx + c * 64) = keep4(xf[c]);
     }
 #ifndef HB_EXP_NO_WGRAD
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -630,14 +674,19 @@ int launch_head(const HeadP& p, bool backward, hipStream_t s) {
     hipLaunchKernelGGL((head_fwd_kernel<T, KS, NCH>), dim3((unsigned)wgs), dim3(256), 0, s, p);
   } else {
     constexpr int STRIP = 32 * (3 * 64 + NCH * 64);
-    const size_t lds = BWD_WAVES * (size_t)STRIP + (size_t)(HeadDim<KS>::NT * NCH + NCH * 2) * 1024;
+    const size_t lds = BWD_WAVES * (size_t)STRIP + (size_t)(HeadDim<KS>::NT * NCH + NCH * 2 + 4 * HeadDim<KS>::NT) * 1024;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    if (!set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      set = true;
+    }
     long wgs = (long)head_cus();                       // persistent: one flush of the gradient tiles per workgroup
     const long steps = (p.npix + 31) / 32;
     if (wgs * BWD_WAVES > steps) wgs = (steps + BWD_WAVES - 1) / BWD_WAVES;
     if (wgs < 1) wgs = 1;
-    hipLaunchKernelGGL((head_bwd_kernel<T, KS, NCH>), dim3((unsigned)wgs), dim3(BWD_WAVES * 64), lds, s, p);
+    if (p.accumulate) hipLaunchKernelGGL((head_bwd_kernel<T, KS, NCH, true>), dim3((unsigned)wgs), dim3(BWD_WAVES * 64), lds, s, p);
+    else hipLaunchKernelGGL((head_bwd_kernel<T, KS, NCH, false>), dim3((unsigned)wgs), dim3(BWD_WAVES * 64), lds, s, p);
   }
   DD_LAUNCH_CHECK();
   return DD_OK;
