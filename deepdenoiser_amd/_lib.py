@@ -22,7 +22,7 @@ SYMBOLS = (
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
-    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_assemble_input", "dd_conv3x3_bwd", "dd_convt2x2_fwd", "dd_convt2x2_bwd",
+    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_assemble_input", "dd_conv3x3_bwd", "dd_convt2x2_fwd", "dd_convt2x2_bwd", "dd_conv3x3_ks",
 )
 
 
@@ -62,6 +62,16 @@ class ConvTArgs(C.Structure):
                 ("bias", C.c_void_p), ("relu", C.c_int),
                 ("dx", C.c_void_p), ("ld_dx", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p), ("use_mask", C.c_int), ("accumulate", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
+
+
+class ConvKsArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("cin", C.c_int),
+                ("wp", C.c_void_p), ("n_pad", C.c_int), ("k_pad", C.c_int),
+                ("bias", C.c_void_p), ("nbias", C.c_int),
+                ("y", C.c_void_p), ("ldy", C.c_int),
+                ("n0", C.c_int), ("n", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("mode", C.c_int), ("flags", C.c_int), ("dtype", C.c_int)]
 
 
 class PackDesc(C.Structure):
@@ -198,6 +208,7 @@ def load():
     lib.dd_conv3x3_bwd.argtypes = [C.POINTER(ConvBwdArgs), vp]
     lib.dd_convt2x2_fwd.argtypes = [C.POINTER(ConvTArgs), vp]
     lib.dd_convt2x2_bwd.argtypes = [C.POINTER(ConvTArgs), vp]
+    lib.dd_conv3x3_ks.argtypes = [C.POINTER(ConvKsArgs), vp]
     lib.dd_colsum.argtypes = [vp, i, i, l, vp, i, vp]
     lib.dd_maxpool_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, i, vp]
     lib.dd_maxpool_bwd.argtypes = [vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, i, i, vp]

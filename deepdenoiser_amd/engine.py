@@ -358,6 +358,23 @@ class Graph:
         run.info = self.convt_records[-1]
         return run
 
+    def _conv_ks_call(self, x, y, layer, wp, n_pad, k_pad, flags, mode=0):
+        """K-streamed 3x3 conv (csrc/dd_conv_ks.hip), one launch: mode 0 = the conv itself, 5 = the 3x3/s2 transposed conv as its four output
+        parities (the library runs channel blocks and parities as sub-problems of one grid)."""
+        ps, lib = self.params, self.lib
+        a = L.ConvKsArgs()
+        a.x, a.ldx, a.cin = x.ptr, x.ld, x.C
+        a.wp, a.n_pad, a.k_pad = wp.data_ptr(), n_pad, k_pad
+        a.bias, a.nbias = ps.value_ptr(layer.bias), layer.cout
+        a.y, a.ldy = y.ptr, y.ld
+        a.n0, a.n = 0, round_up(layer.cout, 4)
+        a.B, a.H, a.W = x.B, x.H, x.W
+        a.mode, a.flags, a.dtype = mode, flags, self.code
+
+        def run(stream, a=a, keep=(x.buf, y.buf, wp)):
+            L.check(lib.dd_conv3x3_ks(C.byref(a), stream))
+        return run
+
     def _bias_grad_call(self, gy, cout, bias_param):
         lib, code, ps = self.lib, self.code, self.params
 
@@ -391,6 +408,21 @@ class Graph:
                                                          x.B, x.H, x.W, flags & L.IN_RELU, nk=(layer.cout, split_at)), "conv_igemm"))
             self.fwd(self._defer(lambda: self._conv_call(xb, wb, taps, n_pad, kb_pad, None, 0, part, None, y,
                                                          x.B, x.H, x.W, flags, nk=(layer.cout, layer.cin - split_at)), "conv_igemm"))
+        elif (self.dtype in ("bf16", "f16") and layer.k == 3 and res is None and (in_relu or layer.cin > 128) and layer.cout % 4 == 0 and layer.cout <= 256
+              and x.ld % 8 == 0 and y.ld % 4 == 0 and x.ch0 % 8 == 0 and y.ch0 % 4 == 0 and os.environ.get("DD_CONV_KS", "1") != "0"):
+            # Tiramisu's dense-block convs (pre-activation, reduction over the growing concat: K = 9 x up to 1 088 channels, 16 ... 128 new
+            # channels): both operands streamed per 64-channel K-slice (csrc/dd_conv_ks.hip); the LDS-weight kernel can keep none of it resident
+            wp, taps, n_pad, k_pad = layer.packed("fwd")
+            rec = {"flops": 2.0 * x.B * x.H * x.W * 9 * layer.cin * layer.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "n": layer.cout, "k": layer.cin,
+                   "extra_reads": 0, "flags": flags}
+            self.conv_records.append(rec)
+
+            def ks_fwd(stream, cell=[]):
+                if not cell:
+                    cell.append(self._conv_ks_call(x, y, layer, wp, n_pad, k_pad, flags))
+                cell[0](stream)
+            ks_fwd.tag, ks_fwd.info = "conv_igemm", rec
+            self.fwd(ks_fwd)
         else:
             wp, taps, n_pad, k_pad = layer.packed("fwd")
             self.fwd(self._defer(lambda: self._conv_call(x, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, res, None, y,
@@ -512,18 +544,35 @@ class Graph:
         """tf.layers.conv2d_transpose(3x3, strides 2, SAME) + ReLU (Tiramisu.py:60-65) as a 3x3 SAME conv of the
         zero-stuffed input (x[i,j] placed at (2i+1, 2j+1)) with the flipped kernel (o = 2i + a)."""
         assert layer.kind == "convT3" and x.C == layer.cin
-        z = self.tensor(x.B, 2 * x.H, 2 * x.W, x.C, requires_grad=x.requires_grad)
-        lib, code = self.lib, self.code
-
-        def stuff(stream):
-            L.check(lib.dd_zero_stuff(x.ptr, x.ld, z.ptr, z.ld, x.Cp, x.B, x.H, x.W, code, stream))
-        self.fwd(stuff)
         y = out if out is not None else self.tensor(x.B, 2 * x.H, 2 * x.W, layer.cout, relu=relu)
         y.relu = relu
         ps = self.params
+        lib, code = self.lib, self.code
         wp, taps, n_pad, k_pad = layer.packed("fwd")
-        self.fwd(self._defer(lambda: self._conv_call(z, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, y,
-                                                     z.B, z.H, z.W, L.OUT_RELU if relu else 0, nk=(layer.cout, layer.cin)), "conv_igemm"))
+        # bf16 / f16: the FORWARD runs as the four output-parity sub-convolutions on the input grid (9 real taps instead of 36, no stuffed tensor:
+        # csrc/dd_conv_ks.hip modes 1..4); the backward still differentiates the zero-stuffed form, so a training graph keeps the stuffed copy
+        parity = (self.dtype in ("bf16", "f16") and layer.cout % 4 == 0 and layer.cout <= 128 and x.ld % 8 == 0 and y.ld % 4 == 0 and x.ch0 % 8 == 0 and y.ch0 % 4 == 0
+                  and os.environ.get("DD_CONVT3_PARITY", "1") != "0")
+        need_z = (not parity) or bool(getattr(self, "training", True))
+        z = self.tensor(x.B, 2 * x.H, 2 * x.W, x.C, requires_grad=x.requires_grad) if need_z else None
+        if need_z:
+            def stuff(stream):
+                L.check(lib.dd_zero_stuff(x.ptr, x.ld, z.ptr, z.ld, x.Cp, x.B, x.H, x.W, code, stream))
+            self.fwd(stuff)
+        if parity:
+            rec = {"flops": 2.0 * x.B * x.H * x.W * 9 * layer.cin * layer.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "n": layer.cout, "k": layer.cin,
+                   "extra_reads": 0, "flags": L.OUT_RELU if relu else 0}
+            self.conv_records.append(rec)
+
+            def ks_convt(stream, cell=[]):
+                if not cell:
+                    cell.append(self._conv_ks_call(x, y, layer, wp, n_pad, k_pad, L.OUT_RELU if relu else 0, mode=5))
+                cell[0](stream)
+            ks_convt.tag, ks_convt.info = "conv_igemm", rec
+            self.fwd(ks_convt)
+        else:
+            self.fwd(self._defer(lambda: self._conv_call(z, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, y,
+                                                         z.B, z.H, z.W, L.OUT_RELU if relu else 0, nk=(layer.cout, layer.cin)), "conv_igemm"))
 
         def backward():
             if not y.grad_written:

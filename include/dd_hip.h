@@ -130,6 +130,29 @@ typedef struct {
 int dd_convt2x2_fwd(const dd_convt_args* a, dd_stream stream);
 int dd_convt2x2_bwd(const dd_convt_args* a, dd_stream stream);
 
+/* ---- K-streamed 3x3 convolution for deep reductions and few output channels: the dense blocks of the Tiramisu backbone
+ * (tf.layers.conv2d over the growing concat, Tiramisu.py:26-41: K = 9 x up to 1 088 channels, 16 ... 128 new channels) and its 3x3 / stride-2
+ * transposed convolution (tf.layers.conv2d_transpose(filters, 3, strides=2, padding='same'), Tiramisu.py:60-65).  bf16 / f16 storage.
+ *   mode 0: y[p][n0 + c] = act(bias[n0 + c] + sum_{t,ci} w[t][n0 + c][ci] * in(x[p + off(t)][ci])),  c < n,  in = relu if DD_IN_RELU;
+ *           w = the dd_pack_weights image [9][n_pad][k_pad] dd_conv_igemm takes, x [B,H,W,ldx], y [B,H,W,ldy] (a channel view of a concat buffer).
+ *   mode 1..4: output parity (py, px) = ((mode-1)/2, (mode-1)%2) of the transposed conv (o = 2i + a, rows / columns 2H, 2W dropped):
+ *           y[2i+py][2j+px][n0 + c] = act(bias + sum over the taps a = py, b = px (mod 2) of x[i - a/2][j - b/2][ci] K[a][b][n0 + c][ci]),
+ *           y [B,2H,2W,ldy]; w = the image dd_pack_weights builds for the zero-stuffed form of the same layer ([9][n_pad][k_pad], taps flipped):
+ *           the four parities together ARE the layer, with the 9 real taps instead of 36;
+ *   mode 5: all four parities in one launch.
+ * One call covers output channels [n0, n0 + n), n <= 256 (mode 5: n <= 128): channel blocks of 64 / 32 / 16 (a 96-channel layer = 64 + 32) and
+ * the parities run as sub-problems of ONE grid (blockIdx.y); the input is re-read per block, from L2. */
+typedef struct {
+  const void* x; int ldx; int cin;
+  const void* wp; int n_pad; int k_pad;
+  const float* bias; int nbias;        /* bias[c] for c < nbias; NULL: none */
+  void* y; int ldy;
+  int n0; int n;
+  int B, H, W;                         /* INPUT grid */
+  int mode; int flags; int dtype;      /* flags: DD_IN_RELU (mode 0 only) | DD_OUT_RELU */
+} dd_conv_ks_args;
+int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream);
+
 /* column sums: out[c] += sum_rows x[row*ld + c]  (bias gradients; embedding-row gradients) */
 int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream);
 

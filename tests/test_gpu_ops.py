@@ -74,6 +74,28 @@ def test_conv_fwd_bwd(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x
     _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B=2)
 
 
+# the K-streamed kernel (csrc/dd_conv_ks.hip): Tiramisu's dense-block convs -- pre-activation, reduction over up to 1 088 channels, 16 ... 128 new
+# channels written into a channel range of the concat buffer; channel blocks 64 + 32, ragged tiles, one to 17 K-slices, partial last slice
+KS_CASES = [
+    # cin, cout, H, W, B
+    (576, 64, 32, 32, 2),
+    (320, 96, 20, 28, 2),
+    (1088, 128, 16, 16, 1),
+    (144, 16, 40, 24, 1),
+    (304, 24, 17, 33, 2),
+    (200, 32, 16, 16, 3),
+    (160, 48, 16, 16, 1),
+    (16, 16, 35, 18, 2),
+    (72, 64, 16, 48, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,B", KS_CASES)
+def test_conv_k_streamed_dense_block_layers(eng, dtype, cin, cout, H, W, B):
+    _conv_case(eng, dtype, 3, cin, cout, H, W, False, True, False, False, B=B, expect_fwd_tag="ks_fwd")
+
+
 # the fused data + weight gradient launch (csrc/dd_conv_bwd.hip: 3x3, <= 64 output channels, bf16 / f16 storage; f32 runs the two-launch path)
 FUSED_BWD_CASES = [
     (64, 64, 32, 32, True, 2),        # the U-Net body layer: every wave of both roles busy
@@ -113,7 +135,8 @@ def test_conv_over_skip_concat_runs_as_two_resident_launches(eng, dtype, cin, co
     _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, split_at=split_at)
 
 
-def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None, expect_fused_bwd=False, x_requires_grad=True):
+def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None, expect_fused_bwd=False, x_requires_grad=True,
+               expect_fwd_tag=None):
     gen = _gen(k * 1000 + cin + cout)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, cin, relu=x_relu, requires_grad=x_requires_grad)
@@ -134,6 +157,8 @@ def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, 
     g.finalize()
     if expect_fused_bwd:
         assert [getattr(op, "tag", "") for op in g.bwd_ops] == ["conv_bwd"], "the fused backward did not engage"
+    if expect_fwd_tag is not None:
+        assert [op.__name__ for op in g.fwd_ops] == [expect_fwd_tag], "the forward did not take the expected kernel"
     wv = representable(torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) / (k * cin ** 0.5), dtype)
     bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
     set_param(g.params, lay.kernel, wv)
@@ -260,8 +285,10 @@ def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-def test_conv_transpose_3x3(eng, dtype):
-    B, H, W, cin, cout = 2, 8, 8, 64, 24
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 64, 24), (1, 17, 21, 200, 96), (2, 16, 16, 136, 64), (1, 9, 35, 40, 16), (1, 16, 16, 1216, 96)])
+def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout):
+    """tf.layers.conv2d_transpose(3x3, strides 2, SAME).  bf16 / f16: the forward runs as the four output-parity sub-convolutions of
+    csrc/dd_conv_ks.hip (9 real taps on the input grid), the backward on the zero-stuffed form; f32: both on the zero-stuffed form."""
     gen = _gen(33)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, cin, requires_grad=True)
@@ -270,6 +297,7 @@ def test_conv_transpose_3x3(eng, dtype):
     y.mark_grad_written()
     g.build_backward()
     g.finalize()
+    assert ("ks_convt" in [getattr(op, "__name__", "") for op in g.fwd_ops]) == (dtype != "f32")
     xv = representable(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64), dtype)
     wv = representable(torch.randn(3, 3, cout, cin, generator=gen, dtype=torch.float64) / (3 * cin ** 0.5), dtype)
     bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()

@@ -1,5 +1,5 @@
 """Per-launch breakdown of one training step (HIP events): which layers cost what, at what TFLOP/s.
-    python tools/step_breakdown.py [bf16|f32] [B] [cfg2|cfg3|cfg1]"""
+    python tools/step_breakdown.py [bf16|f32] [B] [cfg2|cfg3|cfg3h|cfg1]      (cfg3h: the heavy Tiramisu, F = [64, 96, 128])"""
 import os
 import sys
 
@@ -13,9 +13,10 @@ from deepdenoiser_amd.architecture import Architecture  # noqa: E402
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
-aj = {"cfg2": configs.cfg2_unet_kpcn, "cfg3": configs.cfg3_tiramisu, "cfg1": configs.cfg1_small_unet}[cfg]()
+aj = {"cfg2": configs.cfg2_unet_kpcn, "cfg3": configs.cfg3_tiramisu, "cfg3h": lambda: configs.cfg3_tiramisu(filters=(64, 96, 128)),
+      "cfg1": configs.cfg1_small_unet}[cfg]()
 tj = configs.bench_training()
-T = {"cfg2": 128, "cfg3": 256, "cfg1": 64}[cfg]
+T = {"cfg2": 128, "cfg3": 256, "cfg3h": 256, "cfg1": 64}[cfg]
 arch = Architecture(aj, device="cuda", dtype=dtype, seed=2)
 prog = arch.program(B, T, T, training_json=tj)
 feats, labels = synthetic_inputs(arch, B, T, T, "cuda", 1)
