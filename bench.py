@@ -151,34 +151,105 @@ def inference_bench(args, device, rank, world):
                           "config": {"workload": "BASELINE config 5: full-frame 1920x1080 inference, 209 halo tiles (overlap 14), tiles per batch %d" % args.batch}}))
 
 
+def _timed_steps(trainer, steps, warmup):
+    for _ in range(warmup):
+        trainer.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _conv_roofline(prog, peak):
+    """MFMA conv launches of one step of `prog` (HIP events per launch): algorithmic FLOPs / their time, and the step's launch-time total."""
+    times = prog.profile_ops(repeats=2)
+    convs = {k: v for k, v in times.items() if k in ("conv_igemm", "conv_bwd", "conv_wgrad", "convt") and v[1] > 0}
+    ms, fl = sum(v[1] for v in convs.values()), sum(v[2] for v in convs.values())
+    return {"bound": "mfma", "kernel": "all MFMA conv launches of the step", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": fl / (ms * 1e-3) / 1e12 / peak, "conv_ms_per_step": round(ms, 3), "all_launches_ms_per_step": round(sum(v[1] for v in times.values()), 3),
+            "algorithmic_gflop_per_step": fl / 1e9, "families_ms": {k: round(v[1], 3) for k, v in times.items()}}
+
+
 def extras(device, B, H, W):
     """Secondary measurements carried by the default line so that the driver's record holds them too (BASELINE.json's metric also names
-    "inference MPix/s"; the 1e-4 parity gate applies to the f32 storage path, whose throughput is reported beside the bf16 one)."""
+    "inference MPix/s"; the 1e-4 parity gate applies to the f32 storage path, whose throughput is reported beside the bf16 one; BASELINE
+    config 3 = Tiramisu + MultiScalePrediction at 256x256; the literal ArchitectureExample.json = 17 weight-shared tuple passes per tile)."""
     from deepdenoiser_amd import configs
     from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.prediction import Predictor
+    from deepdenoiser_amd.naming import Naming
     from deepdenoiser_amd.training import Trainer
     out = {}
     steps = 10
     dt = inference_frames(device, "f16", 128, 256, steps, 2, 7)
     out["inference"] = {"metric": "inference MPix/s (1920x1080 frame, 209 halo tiles of 128x128x32ch, fp16 MFMA path, output pixels)",
                         "value": steps * 1080 * 1920 / dt / 1e6, "unit": "MPix/s", "ms_per_frame": 1e3 * dt / steps, "dtype": "f16", "frames": steps}
+    try:        # roofline of the inference frame: per-launch HIP events of the forward program of the 209-tile batch
+        arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype="f16", seed=2)
+        pred = Predictor(arch, tile_size=128, tile_overlap_size=14, tiles_per_batch=256)
+        pred.prepare(1080, 1920)
+        prog = pred._plans[(1080, 1920)][1]
+        times = prog.profile_ops(repeats=2)
+        fl = times.get("conv_igemm", (0, 0.0, 0.0))[2]
+        ms_conv = times.get("conv_igemm", (0, 1e-9, 0.0))[1]
+        ms_all = sum(v[1] for v in times.values())
+        out["inference"]["roofline"] = {
+            "bound": "mfma", "kernel": "3x3 / transposed conv launches of the frame's forward (209 tiles, 1.65x halo recompute included in the FLOPs)",
+            "achieved": fl / (ms_conv * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms_conv * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+            "conv_ms_per_frame": round(ms_conv, 3), "whole_frame": {"tflops": fl / (1e-3 * out["inference"]["ms_per_frame"]) / 1e12,
+                                                                   "frac": fl / (1e-3 * out["inference"]["ms_per_frame"]) / 1e12 / PEAK_BF16_TFLOPS},
+            "families_ms": {k: round(v[1], 3) for k, v in times.items()}, "launch_time_ms_per_frame": round(ms_all, 3)}
+        del pred, prog, arch
+    except Exception as e:      # the secondary measurement must never take the headline line down
+        out["inference"]["roofline"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     Bf = min(B, 32)
     arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype="f32", seed=2)
     trainer = Trainer(arch, configs.bench_training(), Bf, H, W, world_size=1, use_graph=True)
     feats, labels = synthetic_inputs(arch, Bf, H, W, device, seed=1000)
     trainer.program.set_inputs(feats, labels)
-    for _ in range(3):
-        trainer.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    steps = 5
-    for _ in range(steps):
-        trainer.step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = _timed_steps(trainer, 5, 3)
     out["f32_path"] = {"metric": "train tiles/sec on the f32 storage path (exact-f32 MFMA; the path the 1e-4 parity gate applies to)",
-                       "value": Bf * steps / dt, "unit": "tiles/s", "ms_per_step": 1e3 * dt / steps, "tiles_per_step": Bf, "dtype": "f32"}
+                       "value": Bf / dt, "unit": "tiles/s", "ms_per_step": 1e3 * dt, "tiles_per_step": Bf, "dtype": "f32"}
+    del trainer, arch
+    torch.cuda.empty_cache()
+    # ---- BASELINE config 3: Tiramisu (FC-DenseNet) + MultiScalePrediction, 256x256 tiles, training step, bf16
+    out["cfg3"] = {}
+    for name, filters, Bc in (("tiramisu_16_24_32", (16, 24, 32), 8), ("tiramisu_64_96_128_heavy", (64, 96, 128), 8)):
+        try:
+            arch = Architecture(configs.cfg3_tiramisu(filters=filters, convs=4), device=device, dtype="bf16", seed=2)
+            trainer = Trainer(arch, configs.bench_training(), Bc, 256, 256, world_size=1, use_graph=True)
+            feats, labels = synthetic_inputs(arch, Bc, 256, 256, device, seed=1000)
+            trainer.program.set_inputs(feats, labels)
+            dt = _timed_steps(trainer, 5, 3)
+            roof = _conv_roofline(trainer.program, PEAK_BF16_TFLOPS)
+            out["cfg3"][name] = {"metric": "train tiles/sec (256x256x32ch Tiramisu F=%s x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction)" % (list(filters),),
+                                 "value": Bc / dt, "unit": "tiles/s", "ms_per_step": 1e3 * dt, "tiles_per_step": Bc, "dtype": "bf16",
+                                 "parameters": int(arch.params.total), "roofline": roof,
+                                 "whole_step": {"tflops": roof["algorithmic_gflop_per_step"] / (1e3 * dt) / 1e3, "frac": roof["algorithmic_gflop_per_step"] / (1e3 * dt) / 1e3 / PEAK_BF16_TFLOPS}}
+            del trainer, arch
+        except Exception as e:
+            out["cfg3"][name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    # ---- the literal ArchitectureExample.json + TrainingExample.json: 17 SINGLE tuples sharing the backbone weights (folded into the batch),
+    #      C_in = 16 with EMBEDDING flags (and their gradient), feature / combined (x5) / image (x10) losses; B = 8 tiles -> 136 tuple passes
+    try:
+        Be = 8
+        arch = Architecture(configs.example_architecture(), device=device, dtype="bf16", seed=2)
+        trainer = Trainer(arch, configs.training(), Be, H, W, world_size=1, use_graph=True)
+        feats, labels = synthetic_inputs(arch, Be, H, W, device, seed=1000)
+        trainer.program.set_inputs(feats, labels)
+        dt = _timed_steps(trainer, 10, 3)
+        out["example_json"] = {"metric": "train tiles/sec of the literal ArchitectureExample.json / TrainingExample.json (17 tuple passes per tile, measured)",
+                               "value": Be / dt, "unit": "tiles/s", "ms_per_step": 1e3 * dt, "tiles_per_step": Be, "tuple_passes_per_step": Be * trainer.program.T,
+                               "tuple_passes_per_s": Be * trainer.program.T / dt, "input_channels": arch.input_channels(), "dtype": "bf16",
+                               "fused_head": bool(trainer.program.fused_head)}
+        del trainer, arch
+    except Exception as e:
+        out["example_json"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
     return out
 
 

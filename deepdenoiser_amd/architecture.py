@@ -11,6 +11,7 @@ MI355X-first differences from the reference's graph (results are the same, SURVE
   * standardize + variance + concat (+ embedding broadcast) are one prepare kernel per pass and one gather kernel.
 """
 
+import copy
 import ctypes as C
 import json
 import math
@@ -174,11 +175,16 @@ class Architecture:
     def program(self, B, H, W, training_json=None, architecture_json=None):
         """Static launch program for a (batch, tile size[, training settings]) configuration (cached)."""
         # keyed on the CONTENT of the training settings: a mutated or re-created dict must not alias a stale program / loss descriptor
-        tkey = None if training_json is None else json.dumps(training_json, sort_keys=True, default=str)
+        # (the learning rate is read at every optimizer step, not baked into the launch program: a schedule must not build a program per value)
+        tkey = None
+        if training_json is not None:
+            tkey = json.dumps({k: v for k, v in training_json.items() if k != "learning_rate"}, sort_keys=True, default=str)
         key = (B, H, W, tkey)
         if key not in self._programs:
             from .program import Program
-            self._programs[key] = Program(self, B, H, W, None if training_json is None else json.loads(json.dumps(training_json)))
+            self._programs[key] = Program(self, B, H, W, None if training_json is None else copy.deepcopy(training_json))
+        elif training_json is not None:
+            self._programs[key].training_json["learning_rate"] = training_json["learning_rate"]
         return self._programs[key]
 
     def predict(self, features, mode=ModeKeys.PREDICT):

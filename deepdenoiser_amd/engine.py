@@ -437,6 +437,7 @@ class Graph:
             # (more than 64 output channels: dd_conv3x3_bwd runs one launch per 64 of them, each re-reading x and re-writing dx -- measured
             #  slower than the register-weight data gradient + the weight-gradient role: 4.80 against 4.10 ms per step; opt-in only)
             wide_ok = layer.cout <= 64 or (x.requires_grad and os.environ.get("DD_FUSE_CONV_BWD_WIDE", "0") != "0")
+            wide_ok = wide_ok and x.B * x.H * x.W < (1 << 23)      # dd_conv3x3_bwd's own limit (linear pixel index in the DMA swizzle): larger problems split
             if (layer.k == 3 and self.dtype in ("bf16", "f16") and wide_ok and not in_relu and (x.requires_grad or layer.cin >= 16)
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):
                 if x.requires_grad:
@@ -453,7 +454,7 @@ class Graph:
                     self._masked_add_bwd(res, gy)
                 return
             wflags = L.IN_RELU if in_relu else 0
-            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 64 and not in_relu and layer.cin >= 16
+            if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 64 and not in_relu and layer.cin >= 16 and x.B * x.H * x.W < (1 << 23)
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0" and os.environ.get("DD_WGRAD_VIA_BWD", "1") != "0"):
                 # > 64 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair of 64 x 64
                 # channels (dx = NULL).  Measured faster than the dedicated weight-gradient kernel: 96->96 at 64x64 154 -> 115 us,

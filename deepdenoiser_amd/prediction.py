@@ -87,8 +87,11 @@ class Predictor:
             if fr.dim() != 3 or fr.shape[2] < f.number_of_channels or tuple(fr.shape[:2]) != (H, W):
                 raise ValueError("%s: expected a [%d,%d,>=%d] frame, got %s" % (f.name, H, W, f.number_of_channels, tuple(fr.shape)))
         flag_frames = {}
-        for name in prog.flags_raw:
+        for name, buf in prog.flags_raw.items():
             key = Naming.feature_flags_name(name)
+            if key not in features:      # the constant one-hot plane (Prediction.py:108): rewritten per frame, a previous caller's planes must not linger
+                buf.zero_()
+                buf[..., arch.feature_flag_names.index(name)] = 1.0
             if key in features:
                 fr = torch.as_tensor(features[key], dtype=torch.float32).to(dev).contiguous()
                 if tuple(fr.shape) != (H, W, prog.flags_raw[name].shape[3]):

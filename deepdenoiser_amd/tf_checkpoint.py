@@ -284,7 +284,9 @@ def _adam_step_from_powers(ck, beta1, beta2, global_step):
     tiny = float(np.finfo(np.float32).tiny)
     if tiny * 1e3 < b1p < 1.0:
         return max(int(round(np.log(b1p) / np.log(beta1))) - 1, 0)
-    if b1p >= 1.0:
+    if b1p == 1.0:      # a step-0 file written by the first revisions of this module (they stored beta ** t; TensorFlow stores beta ** (t + 1))
+        return 0
+    if b1p > 1.0:
         raise CheckpointError("beta1_power = %r is not a power of beta1 = %r" % (b1p, beta1))
     if tiny * 1e3 < b2p < 1.0:
         t = int(round(np.log(b2p) / np.log(beta2))) - 1
