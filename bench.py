@@ -228,7 +228,7 @@ def extras(device, B, H, W):
             out["cfg3"][name] = {"metric": "train tiles/sec (256x256x32ch Tiramisu F=%s x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction)" % (list(filters),),
                                  "value": Bc / dt, "unit": "tiles/s", "ms_per_step": 1e3 * dt, "tiles_per_step": Bc, "dtype": "bf16",
                                  "parameters": int(arch.params.total), "roofline": roof,
-                                 "whole_step": {"tflops": roof["algorithmic_gflop_per_step"] / (1e3 * dt) / 1e3, "frac": roof["algorithmic_gflop_per_step"] / (1e3 * dt) / 1e3 / PEAK_BF16_TFLOPS}}
+                                 "whole_step": {"tflops": roof["algorithmic_gflop_per_step"] / (1e3 * dt), "frac": roof["algorithmic_gflop_per_step"] / (1e3 * dt) / PEAK_BF16_TFLOPS}}
             del trainer, arch
         except Exception as e:
             out["cfg3"][name] = {"error": repr(e)}

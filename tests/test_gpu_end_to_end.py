@@ -163,3 +163,47 @@ def test_dataset_to_checkpoint_to_frame(tmp_path):
             assert np.array_equal(saved, got.cpu().numpy())
             checked += 1
     assert checked >= 1
+
+
+def test_cli_train_then_predict(tmp_path):
+    """The two command lines of the reference (Training.py:33-61, Prediction.py:23-53) on this package:
+    `python -m deepdenoiser_amd.train training.json --train_epochs 2` writes a TensorFlow-format checkpoint into the architecture's
+    model_directory, `python -m deepdenoiser_amd.predict architecture.json --input <frame dir>` restores it and writes <Pass>.npy."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    from deepdenoiser_amd.architecture import Architecture
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    aj = configs.architecture(filters=(16, 24), convs=1, flag_mode="NONE")
+    aj["model_directory"] = "model"
+    tj = configs.training(learning_rate=2e-3, batch_size=4)
+    tj.update({"architecture": "architecture.json", "base_tfrecords_directory": "data", "modes": ["training", "validation"], "number_of_source_index_tuples": 1})
+    tj["data_augmentation"] = {"use_rotate_90": True, "use_flip_left_right": False, "use_rgb_permutation": True, "use_normal_rotation": False}
+    json.dump(aj, open(tmp_path / "architecture.json", "w"))
+    json.dump(tj, open(tmp_path / "training.json", "w"))
+    arch = Architecture(aj, device="cpu")
+    base = str(tmp_path / "data")
+    passes, targets, _ = _write_dataset(base, arch)
+    json.dump({"tiles_height_width": T, "number_of_sources_per_example": 1, "source_samples_per_pixel_list": [SPP]}, open(os.path.join(base, "training.json"), "w"))
+    env = dict(os.environ, PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-m", "deepdenoiser_amd.train", str(tmp_path / "training.json"), "--train_epochs", "2", "--dtype", "f32"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "epoch 2: global_step 4" in p.stdout, p.stdout
+    assert tf_checkpoint.latest_checkpoint(str(tmp_path / "model")) is not None
+    frame_dir = tmp_path / "frame_0001_16_0_0"
+    frame_dir.mkdir()
+    rng = np.random.default_rng(5)
+    for name, ch in passes.items():
+        img = rng.random((40, 72, 3)).astype(np.float32)
+        if ch == 1:
+            img[...] = img[..., :1]
+        openexr.write_image(str(frame_dir / ("render_%s_0001.exr" % name)), img)
+    p = subprocess.run([sys.executable, "-m", "deepdenoiser_amd.predict", str(tmp_path / "architecture.json"), "--input", str(frame_dir),
+                        "--tile_size", "32", "--tile_overlap_size", "4", "--dtype", "f32"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    written = [ln for ln in p.stdout.splitlines() if ln.endswith(".npy")]
+    assert len(written) >= len(targets) and all(os.path.exists(w) for w in written)
+    first = np.load(written[0])
+    assert first.shape[:2] == (40, 72) and np.isfinite(first).all()

@@ -174,3 +174,44 @@ def test_half_precision_full_size_error_against_the_plain_oracle_max_gated(dtype
     print("%s storage vs the plain oracle, cfg-2 128x128: gradient rel-L2 median %.3e max %.3e" % (dtype, errs[len(errs) // 2], errs[-1]))
     gate("%s plain-oracle gradient median" % dtype, errs[len(errs) // 2], grad_median_gate)
     gate("%s plain-oracle gradient max" % dtype, errs[-1], grad_max_gate)
+
+
+# ---------------------------------------------------------------------------------------------------------------- BASELINE config 3
+def _plain_training_parity(what, aj, B, H, W, dtype, fwd_gate, loss_gate, grad_median_gate, grad_max_gate):
+    from test_gpu_model import _pair
+    tj = configs.bench_training()
+    oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, dtype, B, H, W, tj)
+    preds = arch.predict(dev)
+    torch.cuda.synchronize()
+    worst = max(check("%s %s scale %d %s" % (what, dtype, s, k), dp[k].cpu(), do[k], fwd_gate) for s, (dp, do) in enumerate(zip(preds, preds_o)) for k in do)
+    loss_o, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+    loss = float(prog.train_step(dev, devl))
+    torch.cuda.synchronize()
+    gate("%s %s loss rel err" % (what, dtype), abs(loss - float(loss_o)) / abs(float(loss_o)), loss_gate)
+    errs = sorted((rel_l2(arch.params.grad(p).cpu() / prog.loss_scale, go), p.name) for p, go in zip(arch.params.params, grads_o) if float(go.norm()) > 0)
+    print("%s, %s: forward worst rel-L2 %.2e, gradient rel-L2 median %.2e max %.2e (%s) over %d tensors" % (what, dtype, worst, errs[len(errs) // 2][0], errs[-1][0], errs[-1][1], len(errs)))
+    gate("%s %s gradient median" % (what, dtype), errs[len(errs) // 2][0], grad_median_gate)
+    gate("%s %s gradient max (%s)" % (what, dtype, errs[-1][1]), errs[-1][0], grad_max_gate)
+    assert torch.isfinite(arch.params.grads).all()
+    return prog
+
+
+def test_cfg3_full_size_training_step_parity_f32():
+    """BASELINE config 3 at its real size: Tiramisu F = [16, 24, 32] x 4 + 5x5 kernel prediction + 3 scales on a 256x256 tile, B = 1: predictions,
+    loss and every parameter gradient of the f32 path against the f64 oracle (round 2 compared the training step at 32x32, n = 2 only)."""
+    _need_gpu()
+    _plain_training_parity("cfg-3 256x256", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 1, 256, 256, "f32", 1e-4, 2e-5, 2e-4, 2e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_cfg3_heavy_filters_deep_reduction_parity(dtype):
+    """The heavy Tiramisu, F = [64, 96, 128] x 4 (12.9 M parameters), on a 64x64 tile: implicit-GEMM reductions up to K = 9 x 1 088 = 9 792 and
+    the 1 216-channel 3x3/s2 transposed convs, forward and training step.  f32: the LDS-weight kernels (<= 1e-4); bf16 / f16: the K-streamed
+    kernel of csrc/dd_conv_ks.hip (17 K-slices, channel blocks 64 + 32, the four-parity transposed conv) at the storage type's own error."""
+    _need_gpu()
+    aj = configs.cfg3_tiramisu(filters=(64, 96, 128), convs=4)
+    gates = {"f32": (1e-4, 2e-5, 5e-4, 5e-3), "bf16": (2.5e-2, 2e-2, 0.12, 0.6), "f16": (3.5e-3, 3e-3, 0.05, 0.3)}[dtype]
+    prog = _plain_training_parity("cfg-3 heavy 64x64", aj, 1, 64, 64, dtype, *gates)
+    if dtype != "f32":
+        names = [getattr(op, "__name__", "") for op in prog.g.fwd_ops]
+        assert names.count("ks_fwd") == 20 and names.count("ks_convt") == 2, "the dense blocks / transposed convs did not take the K-streamed kernel"
