@@ -71,12 +71,14 @@ class ConvKsArgs(C.Structure):
                 ("y", C.c_void_p), ("ldy", C.c_int),
                 ("n0", C.c_int), ("n", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("mode", C.c_int), ("flags", C.c_int), ("dtype", C.c_int)]
+                ("mode", C.c_int), ("flags", C.c_int), ("dtype", C.c_int),
+                ("mask", C.c_void_p), ("ldmask", C.c_int)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("taps", C.c_int), ("n", C.c_int), ("k", C.c_int), ("n_pad", C.c_int),
-                ("k_pad", C.c_int), ("tap_flip", C.c_int), ("s_tap", C.c_long), ("s_n", C.c_long), ("s_k", C.c_long)]
+                ("k_pad", C.c_int), ("tap_flip", C.c_int), ("s_tap", C.c_long), ("s_n", C.c_long), ("s_k", C.c_long),
+                ("dst_ld", C.c_long), ("dst_tap_stride", C.c_long)]
 
 
 class FeatureParams(C.Structure):

@@ -25,8 +25,8 @@
 namespace {
 
 struct KsP {
-  const void* x; const void* wp; const float* bias; void* y;
-  int ldx, ldy, cinv, n_end, n0, n_pad, k_pad, nbias, nslices;
+  const void* x; const void* wp; const float* bias; const void* mask; void* y;
+  int ldx, ldy, ldmask, cinv, n_end, n0, n_pad, k_pad, nbias, nslices;
   int B, H, W, tiles_x, tiles_y, nblk, ksplit;
   int relu, out_mul, out_py, out_px, Hout, Wout;
 };
@@ -34,7 +34,7 @@ struct KsP {
 // channels = 64 + 32) and the four output parities of a transposed conv run side by side instead of as 2 ... 8 launches of a few dozen workgroups.
 constexpr int KS_MAX_SUB = 8;
 struct KsSub { int mode, ct, n0, n_end, nblk, ksplit; };
-struct KsMulti { KsP p; KsSub sub[KS_MAX_SUB]; int in_relu; };
+struct KsMulti { KsP p; KsSub sub[KS_MAX_SUB]; int in_relu, gather; };
 
 typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KS_PW = DD_TILE + 2, KS_PH = DD_TILE + 2, KS_CH = (KS_PW * KS_PH + 7) / 8, KS_BUF = KS_CH * 1024;      // 41 KiB per buffer
@@ -56,7 +56,10 @@ constexpr int ks_t0(int p) { return p == 1 ? 1 : 0; }
 constexpr int ks_t1(int p) { return p < 0 ? 2 : 1; }
 constexpr int ks_src(int p, int t) { return p < 0 ? t : (p == 0 ? (t == 0 ? 0 : 2) : 1); }
 
-template <typename T, int CT, int MODE, bool IN_RELU>
+// GATHER (mode 0 only): the epilogue of a data gradient in gather form -- y = y + (mask > 0 ? sum : 0), no bias, no activation: the gradient of
+// a channel range of a dense-block buffer from ALL the later convs of the block at once (their output gradients are one contiguous channel range =
+// the reduction), masked by the ReLU its consumers apply on read, added to what the consumers outside the block already stored, rounded once.
+template <typename T, int CT, int MODE, bool IN_RELU, bool GATHER = false>
 __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block) {
   static_assert(sizeof(T) == 2, "K-streamed conv: bf16 / fp16 storage");
   static_assert(CT == 1 || CT == 2 || CT == 4, "1, 2 or 4 output-channel tiles per workgroup");
@@ -122,7 +125,7 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
   for (int w = 0; w < NWL; ++w) wA[w] = load_w(w, 0);
   float bv[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bv[e] = (a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
+  for (int e = 0; e < 4; ++e) bv[e] = (!GATHER && a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
   unsigned d0[8];      // haloed pixel (RH*half + yy)*18 + dx + li of the CURRENT buffer
 #pragma unroll
   for (int c = 0; c < 8; ++c) d0[c] = lds_base + (half * RH * PW + li) * DD_LDS_ROW + ((q ^ ((half * RH * PW + li + c) & 7)) << 4);
@@ -191,14 +194,41 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
         const bool col_ok = ch_ok && cur.x0 + li < a.W;
         const int oy0 = (cur.y0 + half * RH) * a.out_mul + a.out_py, ox = (cur.x0 + li) * a.out_mul + a.out_px;
         T* yp = Y + (((long)cur.b * a.Hout + oy0) * a.Wout + ox) * a.ldy + c4;
+        if (GATHER) {
+          const T* mp = reinterpret_cast<const T*>(a.mask) + (((long)cur.b * a.H + cur.y0 + half * RH) * a.W + cur.x0 + li) * a.ldmask + c4;
+          const long mrow = (long)a.W * a.ldmask;
+          constexpr int GB = RH < 4 ? RH : 4;      // rows per batch: their loads first (one exposed round trip per batch), then the arithmetic
 #pragma unroll
-        for (int y = 0; y < RH; ++y) {
-          const f32x4_t v = acc[y];
-          uint2 o2;
-          o2.x = pack2<T>(v[0], v[1]);
-          o2.y = pack2<T>(v[2], v[3]);
-          if (a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
-          if (col_ok && cur.y0 + half * RH + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+          for (int yb = 0; yb < RH; yb += GB) {
+            uint2 mv[GB], ov[GB];
+#pragma unroll
+            for (int y = 0; y < GB; ++y) {
+              const bool ok = col_ok && cur.y0 + half * RH + yb + y < a.H;
+              mv[y] = ok ? *reinterpret_cast<const uint2*>(mp + (yb + y) * mrow) : uint2{0u, 0u};
+              ov[y] = ok ? *reinterpret_cast<const uint2*>(yp + (yb + y) * yrow) : uint2{0u, 0u};
+            }
+#pragma unroll
+            for (int y = 0; y < GB; ++y) {
+              float m8[8], o8[8];
+              unpack8t<T>(uint4{mv[y].x, mv[y].y, 0u, 0u}, m8);
+              unpack8t<T>(uint4{ov[y].x, ov[y].y, 0u, 0u}, o8);
+              const f32x4_t v = acc[yb + y];
+              uint2 o2;
+              o2.x = pack2<T>(o8[0] + (m8[0] > 0.f ? v[0] : 0.f), o8[1] + (m8[1] > 0.f ? v[1] : 0.f));
+              o2.y = pack2<T>(o8[2] + (m8[2] > 0.f ? v[2] : 0.f), o8[3] + (m8[3] > 0.f ? v[3] : 0.f));
+              if (col_ok && cur.y0 + half * RH + yb + y < a.H) *reinterpret_cast<uint2*>(yp + (yb + y) * yrow) = o2;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int y = 0; y < RH; ++y) {
+            const f32x4_t v = acc[y];
+            uint2 o2;
+            o2.x = pack2<T>(v[0], v[1]);
+            o2.y = pack2<T>(v[2], v[3]);
+            if (a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
+            if (col_ok && cur.y0 + half * RH + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+          }
         }
       }
     }
@@ -229,7 +259,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const KsMulti m) {
 #define KS_CASE(CT_, MODE_, RELU_) conv_ks_body<T, CT_, MODE_, RELU_>(a, smem, b)
 #define KS_MODES(CT_)                                                      \
   switch (sb.mode) {                                                       \
-    case 0: if (m.in_relu) KS_CASE(CT_, 0, true); else KS_CASE(CT_, 0, false); break; \
+    case 0: if (m.gather) conv_ks_body<T, CT_, 0, false, true>(a, smem, b);       \
+            else if (m.in_relu) KS_CASE(CT_, 0, true); else KS_CASE(CT_, 0, false); break; \
     case 1: KS_CASE(CT_, 1, false); break;                                 \
     case 2: KS_CASE(CT_, 2, false); break;                                 \
     case 3: KS_CASE(CT_, 3, false); break;                                 \
@@ -258,30 +289,31 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->cin > 0 && a->n > 0 && a->n0 >= 0, "dd_conv3x3_ks: empty problem");
   DD_REQUIRE(a->mode >= 0 && a->mode <= 5, "dd_conv3x3_ks: mode %d (0: 3x3 SAME conv; 1..4: output parity (py, px) = ((mode-1)/2, (mode-1)%%2) of the 3x3/s2 transposed conv; 5: all four)", a->mode);
   DD_REQUIRE(a->mode == 0 || !(a->flags & DD_IN_RELU), "dd_conv3x3_ks: the transposed conv takes no input ReLU");
-  DD_REQUIRE((a->flags & ~(DD_IN_RELU | DD_OUT_RELU)) == 0, "dd_conv3x3_ks: flags %d unsupported (DD_IN_RELU | DD_OUT_RELU)", a->flags);
+  DD_REQUIRE((a->flags & ~(DD_IN_RELU | DD_OUT_RELU | DD_ACCUM)) == 0, "dd_conv3x3_ks: flags %d unsupported (DD_IN_RELU | DD_OUT_RELU | DD_ACCUM)", a->flags);
+  const bool gather = (a->flags & DD_ACCUM) != 0;
+  DD_REQUIRE(!gather || (a->mode == 0 && a->mask && !(a->flags & (DD_IN_RELU | DD_OUT_RELU)) && a->ldmask % 4 == 0 && ((uintptr_t)a->mask % 8) == 0),
+             "dd_conv3x3_ks: DD_ACCUM is the gather-form data gradient: mode 0, a mask tensor (8-byte aligned, ldmask %% 4 == 0), no ReLU flags");
   DD_REQUIRE(a->ldx % 8 == 0 && a->ldy % 4 == 0 && a->k_pad % 32 == 0 && a->n_pad % 16 == 0 && a->n0 % 16 == 0 && a->n % 4 == 0,
              "dd_conv3x3_ks: ldx=%d (%%8) ldy=%d (%%4) k_pad=%d (%%32) n_pad=%d (%%16) n0=%d (%%16) n=%d (%%4)", a->ldx, a->ldy, a->k_pad, a->n_pad, a->n0, a->n);
   DD_REQUIRE(a->n0 + a->n <= a->n_pad && a->cin <= a->k_pad, "dd_conv3x3_ks: channel ranges exceed the packed weight image");
   DD_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0, "dd_conv3x3_ks: x / wp must be 16-byte, y 8-byte aligned");
   KsMulti m;
   KsP& p = m.p;
-  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.y = a->y;
-  p.ldx = a->ldx; p.ldy = a->ldy; p.cinv = (a->cin + 7) / 8 * 8; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldmask = a->ldmask; p.cinv = (a->cin + 7) / 8 * 8; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
   p.nbias = a->nbias; p.nslices = (a->cin + 63) / 64;
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.relu = (a->flags & DD_OUT_RELU) != 0;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
   p.n0 = p.n_end = p.nblk = p.ksplit = p.out_mul = p.out_py = p.out_px = p.Hout = p.Wout = 0;      // per sub-problem, set by the kernel
   m.in_relu = (a->flags & DD_IN_RELU) != 0;
-  // channel blocks of <= 64 channels with the narrowest tile count that covers them (a 96-channel layer = 64 + 32), times the parities
-  int starts[4], widths[4], cts[4], nb = 0;
-  for (int c0 = 0; c0 < a->n; ) {
-    const int left = a->n - c0;
-    const int w = left > 48 ? (left < 64 ? left : 64) : left;      // 49..64 -> one 4-tile block; <= 48 -> the remainder as it is
-    DD_REQUIRE(nb < 4, "dd_conv3x3_ks: more than 256 output channels per call");
-    starts[nb] = c0; widths[nb] = w; cts[nb] = w <= 16 ? 1 : (w <= 32 ? 2 : 4); ++nb;
-    c0 += w;
-  }
+  m.gather = gather ? 1 : 0;
+  // channel blocks: every whole 64 channels as workgroup columns of ONE sub-problem (4 tiles each), the remainder (<= 63 channels) as a
+  // second one with the narrowest tile count that covers it (a 96-channel layer = 64 + 32)
+  int starts[2], widths[2], cts[2], nb = 0;
+  const int whole = a->n / 64 * 64, rest = a->n - whole;
+  if (whole > 0) { starts[nb] = 0; widths[nb] = whole; cts[nb] = 4; ++nb; }
+  if (rest > 0) { starts[nb] = whole; widths[nb] = rest; cts[nb] = rest <= 16 ? 1 : (rest <= 32 ? 2 : 4); ++nb; }
   const int first_mode = a->mode == 5 ? 1 : a->mode, last_mode = a->mode == 5 ? 4 : a->mode;
   const long total = (long)a->B * p.tiles_x * p.tiles_y;
   int ns = 0;
@@ -292,7 +324,7 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
       KsSub& sb = m.sub[ns++];
       sb.mode = mode; sb.ct = cts[b]; sb.n0 = a->n0 + starts[b]; sb.n_end = sb.n0 + widths[b];
       sb.nblk = dd_ceil_div(widths[b], sb.ct * 16);
-      long ksplit = ks_cus() / sb.nblk;
+      long ksplit = dd_ceil_div(ks_cus(), sb.nblk);
       if (ksplit < 1) ksplit = 1;
       if (ksplit > total) ksplit = total;
       sb.ksplit = (int)ksplit;

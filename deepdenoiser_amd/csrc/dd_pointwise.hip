@@ -83,6 +83,7 @@ __global__ void pack_batched_kernel(const dd_pack_desc* __restrict__ table) {
   const dd_pack_desc d = table[blockIdx.y];
   T* dst = reinterpret_cast<T*>(d.dst);
   const long total = (long)d.taps * d.n_pad * d.k_pad;
+  const long ld = d.dst_ld ? d.dst_ld : d.k_pad, tstride = d.dst_tap_stride ? d.dst_tap_stride : (long)d.n_pad * d.k_pad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int kk = (int)(i % d.k_pad);
     const long r = i / d.k_pad;
@@ -90,7 +91,7 @@ __global__ void pack_batched_kernel(const dd_pack_desc* __restrict__ table) {
     const int t = (int)(r / d.n_pad);
     float v = 0.f;
     if (nn < d.n && kk < d.k) v = d.src[(d.tap_flip ? d.taps - 1 - t : t) * d.s_tap + nn * d.s_n + kk * d.s_k];
-    dst[i] = Elem<T>::from_f32(v);
+    dst[t * tstride + nn * ld + kk] = Elem<T>::from_f32(v);
   }
 }
 extern "C" int dd_pack_weights_batched(const dd_pack_desc* table, int n_layers, int dtype, dd_stream stream) {

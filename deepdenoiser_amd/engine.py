@@ -216,16 +216,19 @@ class Graph:
         self._pack_records = []
 
     # ------------------------------------------------------------------ weight packing: every layer in ONE launch
-    def register_pack(self, kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip, src_offset=0):
-        self._pack_records.append((kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip, src_offset))
+    def register_pack(self, kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip, src_offset=0, dst_offset=0, dst_ld=0, dst_tap_stride=0):
+        """dst_offset / dst_ld / dst_tap_stride (elements): this record fills the [n_pad][k_pad] corner at `dst_offset` of every tap of a wider
+        image [taps][n_pad][dst_ld] (stacked reductions: the gather-form data gradient of a dense block)."""
+        self._pack_records.append((kernel, buf, taps, n, k, n_pad, k_pad, st, sn, sk, flip, src_offset, dst_offset, dst_ld, dst_tap_stride))
         if not self.pack_ops:
             state = {}
 
             def pack_all(stream):
                 if state.get("n") != len(self._pack_records):   # (re)build the device table when layers were added
                     tab = (L.PackDesc * len(self._pack_records))()
-                    for i, (kern, b, tp, nn, kk, npad, kpad, s_t, s_n, s_k, fl, off) in enumerate(self._pack_records):
-                        tab[i] = L.PackDesc(self.params.value_ptr(kern) + 4 * off, b.data_ptr(), tp, nn, kk, npad, kpad, fl, s_t, s_n, s_k)
+                    for i, (kern, b, tp, nn, kk, npad, kpad, s_t, s_n, s_k, fl, off, doff, dld, dts) in enumerate(self._pack_records):
+                        tab[i] = L.PackDesc(self.params.value_ptr(kern) + 4 * off, b.data_ptr() + doff * _ESZ[self.dtype], tp, nn, kk, npad, kpad, fl,
+                                            s_t, s_n, s_k, dld, dts)
                     state["dev"] = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
                     state["n"] = len(self._pack_records)
                 L.check(self.lib.dd_pack_weights_batched(state["dev"].data_ptr(), state["n"], self.code, stream))
@@ -383,7 +386,7 @@ class Graph:
         return run
 
     # ------------------------------------------------------------------ differentiable ops
-    def conv(self, x, layer, relu=False, in_relu=False, res=None, out=None, split_at=None):
+    def conv(self, x, layer, relu=False, in_relu=False, res=None, out=None, split_at=None, no_backward=False):
         """tf.layers.conv2d(k x k, SAME) [+ residual] [+ ReLU]; `out` may be a channel view of a concat buffer.
         split_at: x is the concat [x[:, :split_at] | x[:, split_at:]] (the U-Net skip concat).  With more than 128 input channels in
         bf16 the 3x3 weights of a 32-channel block no longer fit LDS and the launch falls to 16-channel blocks (6 passes over the
@@ -474,8 +477,91 @@ class Graph:
                 x.mark_grad_written()
             if res is not None and res.requires_grad:
                 self._masked_add_bwd(res, gy)
-        self.on_backward(backward)
+        if not no_backward:      # (dense_block differentiates its convs together)
+            self.on_backward(backward)
         return y
+
+    # ------------------------------------------------------------------ Tiramisu dense block
+    def dense_block(self, buf, c0, f, layers):
+        """Tiramisu.__dense_block (Tiramisu.py:26-41): conv j reads relu(buf[:, :c0 + j f]) and appends f channels at c0 + j f (the concat is a view).
+
+        Backward.  Layer by layer every conv's data gradient accumulates into the whole prefix it read: the prefix of a block is read, added to and
+        re-written once per conv (O(n^2) traffic), each pass rounding the running sum to the storage type.  Here (bf16 / f16, growth <= 32
+        channels) the block is differentiated in GATHER form: the gradient
+        of a channel range receives the contributions of ALL later convs of the block in ONE launch -- their output gradients are one contiguous
+        channel range of the gradient buffer, i.e. the reduction of a deep-K conv with the stacked transposed kernels (csrc/dd_conv_ks.hip,
+        DD_ACCUM) -- masked by the consumers' ReLU, added to what the consumers outside the block stored, rounded once.  Ranges go last to first
+        (a conv's weight gradient needs its output gradient complete), the block's input prefix last."""
+        n = len(layers)
+        # Measured (B = 8, 256x256): growth 16 / 24 / 32 (BASELINE cfg-3): step 7.81 -> 6.96 ms in gather form; growth 64 / 96 / 128 (the heavy
+        # stress configuration): 23.98 -> 26.45 ms -- there the layer-wise data gradients have K = 9 x 64 ... 128, whose weights stay resident in LDS
+        # (csrc/dd_conv_igemm.hip at ~700 TFLOP/s), while the gather of a 384 ... 800-channel prefix re-streams its operands per 64-channel
+        # block (~400 TFLOP/s).  DD_DENSE_GATHER=1 / 0 forces either form.
+        force = os.environ.get("DD_DENSE_GATHER", "")
+        gather = (self.dtype in ("bf16", "f16") and f % 8 == 0 and c0 % 8 == 0 and buf.ld % 8 == 0 and os.environ.get("DD_CONV_KS", "1") != "0"
+                  and (force == "1" or (force != "0" and f <= 32)))
+        for j, lay in enumerate(layers):
+            cj = c0 + j * f
+            assert lay.cin == cj and lay.cout == f and lay.k == 3
+            self.conv(buf.view(0, cj), lay, relu=False, in_relu=True, out=buf.view(cj, f, relu=False), no_backward=gather)
+        if not gather:
+            return c0 + n * f
+        ps, lib, code = self.params, self.lib, self.code
+
+        def stacked_image(s0, sn, later):
+            """MFMA operand [9][n_pad][k_pad]: row s - s0 (a channel of the target range), column block of conv i = its kernel W_i[8 - tap][s][:]."""
+            n_pad, k_tot = round_up(sn, 16), sum(l.cout for l in later)
+            k_pad = round_up(k_tot, 64 // _ESZ[self.dtype])
+            img = torch.zeros(9 * n_pad * k_pad, dtype=_TORCH_DT[self.dtype], device=self.device)
+            koff = 0
+            for l in later:
+                self.register_pack(l.kernel, img, 9, sn, l.cout, n_pad, l.cout, l.cin * l.cout, l.cout, 1, 1, src_offset=s0 * l.cout,
+                                   dst_offset=koff, dst_ld=k_pad, dst_tap_stride=n_pad * k_pad)
+                koff += l.cout
+            return img, n_pad, k_pad
+
+        plans = []      # (target start, width, first later conv): images are registered now, so that they are packed with every other layer's
+        for j in range(n - 1):
+            plans.append((c0 + j * f, f, j + 1) + stacked_image(c0 + j * f, f, layers[j + 1:]))
+        plans.append((0, c0, 0) + stacked_image(0, c0, layers))
+
+        def backward():
+            gbuf = buf.grad()
+            assert buf.grad_written, "a dense-block buffer accumulates: its gradient storage must be zero-initialised"
+
+            def gather_call(s0, sn, first, img, n_pad, k_pad):
+                kch = (n - first) * f
+                x0 = c0 + first * f
+                rec = {"flops": 2.0 * buf.B * buf.H * buf.W * 9 * kch * sn, "B": buf.B, "H": buf.H, "W": buf.W, "taps": 9, "n": sn, "k": kch,
+                       "extra_reads": 2, "flags": L.ACCUM}
+                self.conv_records.append(rec)
+                a = L.ConvKsArgs()
+                a.x, a.ldx, a.cin = gbuf.ptr + x0 * _ESZ[self.dtype], gbuf.ld, kch
+                a.wp, a.n_pad, a.k_pad = img.data_ptr(), n_pad, k_pad
+                a.bias, a.nbias = None, 0
+                a.y, a.ldy = gbuf.ptr + s0 * _ESZ[self.dtype], gbuf.ld
+                a.mask, a.ldmask = buf.ptr + s0 * _ESZ[self.dtype], buf.ld
+                a.n0, a.n = 0, round_up(sn, 4)
+                a.B, a.H, a.W = buf.B, buf.H, buf.W
+                a.mode, a.flags, a.dtype = 0, L.ACCUM, code
+
+                def dense_gather(stream, a=a, keep=(gbuf.buf, buf.buf, img)):
+                    L.check(lib.dd_conv3x3_ks(C.byref(a), stream))
+                dense_gather.tag, dense_gather.info = "conv_igemm", rec
+                self.bwd(dense_gather)
+
+            for j in reversed(range(n)):
+                lay, cj = layers[j], c0 + j * f
+                if j < n - 1:
+                    gather_call(*plans[j])
+                x, gy = buf.view(0, cj), gbuf.view(cj, f)
+                self.bwd(self._defer(lambda x=x, gy=gy, lay=lay: self._wgrad_call(x, lay.cin, gy, lay.cout, ps.grad_ptr(lay.kernel), x.B, x.H, x.W, 9, L.IN_RELU,
+                                                                                   ps.grad_ptr(lay.bias), 1), "conv_wgrad"), grad_params=[lay.kernel, lay.bias])
+            if buf.requires_grad and c0 > 0:
+                gather_call(*plans[n - 1])
+            buf.mark_grad_written()
+        self.on_backward(backward)
+        return c0 + n * f
 
     def _self_mask(self, y, gy):
         if not y.self_mask:

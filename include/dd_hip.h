@@ -55,7 +55,9 @@ int dd_pack_weights(const float* src, void* dst, int dtype, int taps, int n, int
                     long s_tap, long s_n, long s_k, int tap_flip, dd_stream stream);
 
 /* all layers in ONE launch: `table` is a device array of n records */
-typedef struct { const float* src; void* dst; int taps, n, k, n_pad, k_pad, tap_flip; long s_tap, s_n, s_k; } dd_pack_desc;
+/* dst_ld / dst_tap_stride (elements; 0 = k_pad / n_pad * k_pad): the record fills the [n_pad][k_pad] corner of every tap of a WIDER image
+ * ([taps][n_pad][dst_ld]) -- several records stack their reductions side by side in one operand (the gather-form data gradient of dd_conv3x3_ks) */
+typedef struct { const float* src; void* dst; int taps, n, k, n_pad, k_pad, tap_flip; long s_tap, s_n, s_k; long dst_ld, dst_tap_stride; } dd_pack_desc;
 int dd_pack_weights_batched(const dd_pack_desc* table, int n_layers, int dtype, dd_stream stream);
 
 /* ---- implicit-GEMM convolution on MFMA (forward and data-gradient of every conv-like layer).
@@ -140,8 +142,12 @@ int dd_convt2x2_bwd(const dd_convt_args* a, dd_stream stream);
  *           y [B,2H,2W,ldy]; w = the image dd_pack_weights builds for the zero-stuffed form of the same layer ([9][n_pad][k_pad], taps flipped):
  *           the four parities together ARE the layer, with the 9 real taps instead of 36;
  *   mode 5: all four parities in one launch.
- * One call covers output channels [n0, n0 + n), n <= 256 (mode 5: n <= 128): channel blocks of 64 / 32 / 16 (a 96-channel layer = 64 + 32) and
- * the parities run as sub-problems of ONE grid (blockIdx.y); the input is re-read per block, from L2. */
+ * One call covers output channels [n0, n0 + n) (mode 5: n <= 64 + 63): whole blocks of 64 channels and the remainder (32 / 16-channel tiles: a
+ * 96-channel layer = 64 + 32), and the parities, run as sub-problems of ONE grid (blockIdx.y); the input is re-read per block, from L2.
+ * DD_ACCUM (mode 0) is the data gradient of a Tiramisu dense block in GATHER form (TF autodiff of Tiramisu.py:26-41 behind Training.py:701-702):
+ * the gradient of a channel range of the block's buffer receives the contributions of ALL later convs of the block in one launch -- their output
+ * gradients are one contiguous channel range of the gradient buffer (= x, the reduction), wp the stacked transposed / flipped kernels
+ * (dd_pack_weights_batched with dst_ld) -- masked by the ReLU the consumers apply on read, added to what is already stored, rounded once. */
 typedef struct {
   const void* x; int ldx; int cin;
   const void* wp; int n_pad; int k_pad;
@@ -149,7 +155,8 @@ typedef struct {
   void* y; int ldy;
   int n0; int n;
   int B, H, W;                         /* INPUT grid */
-  int mode; int flags; int dtype;      /* flags: DD_IN_RELU (mode 0 only) | DD_OUT_RELU */
+  int mode; int flags; int dtype;      /* flags: DD_IN_RELU (mode 0 only) | DD_OUT_RELU, or DD_ACCUM alone (gather-form data gradient, below) */
+  const void* mask; int ldmask;        /* DD_ACCUM: y[p][n0+c] += (mask[p][n0+c] > 0) * sum  -- no bias, no activation, rounded once */
 } dd_conv_ks_args;
 int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream);
 

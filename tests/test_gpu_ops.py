@@ -96,6 +96,69 @@ def test_conv_k_streamed_dense_block_layers(eng, dtype, cin, cout, H, W, B):
     _conv_case(eng, dtype, 3, cin, cout, H, W, False, True, False, False, B=B, expect_fwd_tag="ks_fwd")
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("form", ["gather", "scatter"])
+@pytest.mark.parametrize("c0,f,n,H,W,B", [(16, 16, 3, 20, 28, 2), (40, 24, 4, 16, 16, 1), (64, 32, 2, 17, 33, 2), (96, 64, 3, 16, 16, 1)])
+def test_dense_block_backward_gather_and_scatter_forms(eng, dtype, form, c0, f, n, H, W, B, monkeypatch):
+    """engine.Graph.dense_block (Tiramisu.py:26-41): n pre-activation 3x3 convs appending f channels each to a concat buffer, differentiated in
+    gather form (one K-streamed launch per channel range: all later convs' contributions at once, rounded once; csrc/dd_conv_ks.hip DD_ACCUM with
+    stacked weight images) and in scatter form (every conv's data gradient accumulated into its whole prefix).  Against the oracle chain with
+    the storage roundings: forward ranges, the gradient of every channel of the buffer (incl. the contributions from outside the block that
+    are already stored), every kernel and bias gradient."""
+    monkeypatch.setenv("DD_DENSE_GATHER", "1" if form == "gather" else "0")
+    from oracle.model import VarStore
+    gen = _gen(c0 + f + n)
+    g = eng.Graph("cuda", dtype)
+    total = c0 + n * f
+    buf = g.tensor(B, H, W, total, relu=False)
+    buf.gstate["zero_init"] = True
+    layers = [g.layer("d/conv2d_%d" % j, 3, c0 + j * f, f) for j in range(n)]
+    assert g.dense_block(buf, c0, f, layers) == total
+    g.build_backward()
+    g.finalize()
+    tags = [getattr(op, "__name__", "") for op in g.bwd_ops]
+    assert (tags.count("dense_gather") == n) == (form == "gather" and dtype != "f32"), tags
+    xv = representable(torch.randn(B, H, W, c0, generator=gen, dtype=torch.float64), dtype)
+    ws, bs = [], []
+    for lay in layers:
+        w = representable(torch.randn(lay.kernel.shape, generator=gen, dtype=torch.float64) / (3 * lay.cin ** 0.5), dtype)
+        b = torch.randn(lay.cout, generator=gen, dtype=torch.float64).float().double()
+        set_param(g.params, lay.kernel, w); set_param(g.params, lay.bias, b)
+        ws.append(w.clone().requires_grad_(True)); bs.append(b.clone().requires_grad_(True))
+    buf.buf.zero_()
+    buf.buf[..., :c0] = xv.to(buf.buf.dtype).cuda()
+    g.run(g.pack_ops); g.run(g.fwd_ops)
+    torch.cuda.synchronize()
+    emu = VarStore(storage=dtype)
+    xo = xv.clone().requires_grad_(True)
+    parts = [emu.qgrad(xo)]
+    for j in range(n):
+        pre = T.conv2d_same(torch.relu(torch.cat(parts, dim=3)), ws[j], bs[j], False)
+        parts.append(emu.q(emu.qgrad(pre)))
+    full = torch.cat(parts, dim=3)
+    got = buf.buf[..., :total].double().cpu()
+    check("dense block forward", got, full.detach(), ROUND[dtype] * (1 if dtype == "f32" else 2))
+    # gradient arriving from outside the block on every channel (the transition conv, the transposed conv, the heads): already stored
+    G = representable(torch.randn(B, H, W, total, generator=gen, dtype=torch.float64), dtype)
+    for t in g.zero_init_buffers:
+        t.zero_()
+    buf.grad().buf[..., :total] = G.to(buf.buf.dtype).cuda()
+    g.params.grads.zero_()
+    grads = torch.autograd.grad((full * G).sum(), [xo] + ws + bs)
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    # Measured (profiles/r03_parity_errors.txt).  Gather form: every range is rounded ONCE, exactly where the oracle chain rounds it -- the prefix
+    # gradient agrees to 2e-7 ... 6e-5 and dW to 6e-8 ... 6e-5 (the upper end: one stored value on the other side of a rounding boundary).
+    # Scatter form: the running sum is rounded once per contributing conv -- prefix 3.5e-3 (bf16) / 4.4e-4 (fp16), dW up to 3.1e-3 / 3.7e-4.
+    half = dtype != "f32"
+    g_prefix = {True: {"gather": 3e-4, "scatter": 3 * ROUND[dtype]}, False: {"gather": ROUND[dtype], "scatter": ROUND[dtype]}}[half][form]
+    g_dw = {True: {"gather": 3e-4, "scatter": 1.5 * ROUND[dtype]}, False: {"gather": ACC32[dtype], "scatter": ACC32[dtype]}}[half][form]
+    check("d prefix (%s)" % form, buf.grad().buf[..., :c0].double().cpu(), grads[0], g_prefix)
+    for j, lay in enumerate(layers):
+        check("dW %s (%s)" % (lay.name, form), g.params.grad(lay.kernel).double().cpu(), grads[1 + j], g_dw)
+        check("db %s (%s)" % (lay.name, form), g.params.grad(lay.bias).double().cpu(), grads[1 + n + j], g_dw)
+
+
 # the fused data + weight gradient launch (csrc/dd_conv_bwd.hip: 3x3, <= 64 output channels, bf16 / f16 storage; f32 runs the two-launch path)
 FUSED_BWD_CASES = [
     (64, 64, 32, 32, True, 2),        # the U-Net body layer: every wave of both roles busy
