@@ -174,11 +174,14 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
         for (int j = 0; j < FRW; ++j) {
           const int f = yi * FRW + j, txi = j / 2, kc = j & 1;
           if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
-          {      // the next unit's DMA pieces and weight fragments, spread evenly over the NF steps (at most one of each per step)
-            const int k0 = (f * NPIECE + NF - 1) / NF;
-            if (k0 < NPIECE && (k0 * NF) / NPIECE == f) piece(k0, nxt, nsl, nbuf);
-            const int w0 = (f * NWL + NF - 1) / NF;
-            if (w0 < NWL && (w0 * NF) / NWL == f) wn[w0] = load_w(w0, nsl);
+          {      // the next unit's DMA pieces and weight fragments, spread evenly over the NF steps: piece k goes with step (k NF) / NPIECE.
+                 // (A narrow wave -- 2 output rows, one tap -- has FEWER steps than pieces: several pieces per step, none may be dropped.)
+#pragma unroll
+            for (int k = 0; k < NPIECE; ++k)
+              if ((k * NF) / NPIECE == f) piece(k, nxt, nsl, nbuf);
+#pragma unroll
+            for (int w = 0; w < NWL; ++w)
+              if ((w * NF) / NWL == f) wn[w] = load_w(w, nsl);
           }
           __builtin_amdgcn_sched_barrier(0);
           const uint4 b = IN_RELU ? relu16<T>(ring[f % RING]) : ring[f % RING];

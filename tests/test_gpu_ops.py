@@ -87,6 +87,9 @@ KS_CASES = [
     (160, 48, 16, 16, 1),
     (16, 16, 35, 18, 2),
     (72, 64, 16, 48, 1),
+    (168, 16, 16, 16, 1),       # one 16-channel tile, three K-slices: fewer fragment steps per unit than DMA pieces
+    (296, 16, 8, 8, 1),
+    (136, 24, 24, 8, 2),
 ]
 
 
@@ -348,7 +351,8 @@ def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 64, 24), (1, 17, 21, 200, 96), (2, 16, 16, 136, 64), (1, 9, 35, 40, 16), (1, 16, 16, 1216, 96)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 64, 24), (1, 17, 21, 200, 96), (2, 16, 16, 136, 64), (1, 9, 35, 40, 16), (1, 16, 16, 1216, 96),
+                                            (1, 16, 16, 168, 16), (1, 8, 8, 160, 24), (2, 20, 12, 328, 32)])      # narrow outputs over several K-slices
 def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout):
     """tf.layers.conv2d_transpose(3x3, strides 2, SAME).  bf16 / f16: the forward runs as the four output-parity sub-convolutions of
     csrc/dd_conv_ks.hip (9 real taps on the input grid), the backward on the zero-stuffed form; f32: both on the zero-stuffed form."""
