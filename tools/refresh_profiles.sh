@@ -3,7 +3,7 @@
 # Writes gpurun_out/<tag>/...; copy what is to be judged into profiles/ (tools/collect_profiles.py <tag>).
 # Trace and counter passes are separate rocprofv3 runs (never --pmc together with a trace option).
 set -x
-tag=${1:-r02_x}
+tag=${1:-r03_x}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -13,12 +13,23 @@ timeout 300 python bench.py --no-cpu-baseline --no-extras --host-inputs 2>/dev/n
 timeout 300 python bench.py --mode inference --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/inference.json
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- python bench.py --no-cpu-baseline --no-extras > $out/prof.log 2>&1
 python tools/rocprof_summary.py $(ls $out/prof/*/*results.db $out/prof/*results.db 2>/dev/null | head -1) 60 > $out/kernel_stats.txt 2>&1
+# the other half of BASELINE's metric (cfg-5 inference, fp16) and BASELINE config 3 (heavy Tiramisu) under the same profiler
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_inf -o inf -- python bench.py --mode inference --steps 10 --warmup 2 > $out/prof_inf.log 2>&1
+python tools/rocprof_summary.py $(ls $out/prof_inf/*/*results.db $out/prof_inf/*results.db 2>/dev/null | head -1) 40 > $out/inference_kernel_stats.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_cfg3 -o cfg3 -- python tools/cfg3_step.py heavy 8 5 > $out/prof_cfg3.log 2>&1
+python tools/rocprof_summary.py $(ls $out/prof_cfg3/*/*results.db $out/prof_cfg3/*results.db 2>/dev/null | head -1) 40 > $out/cfg3_heavy_kernel_stats.txt 2>&1
+tail -1 $out/prof_cfg3.log >> $out/cfg3_heavy_kernel_stats.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_cfg3l -o cfg3l -- python tools/cfg3_step.py light 8 5 > $out/prof_cfg3l.log 2>&1
+python tools/rocprof_summary.py $(ls $out/prof_cfg3l/*/*results.db $out/prof_cfg3l/*results.db 2>/dev/null | head -1) 40 > $out/cfg3_light_kernel_stats.txt 2>&1
+tail -1 $out/prof_cfg3l.log >> $out/cfg3_light_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $c -d $out/pmc_$n -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-extras --no-graph --steps 2 --warmup 1 > $out/pmc_$n.log 2>&1
-  python tools/pmc_family.py $out/pmc_$n conv_igemm conv_rw wgrad_dma conv_bwd convt_fwd convt_bwd compose_fwd compose_bwd head_fwd head_bwd > $out/pmc_$n.txt 2>&1
+  python tools/pmc_family.py $out/pmc_$n conv_igemm conv_rw conv_ks wgrad_dma conv_bwd convt_fwd convt_bwd compose_fwd compose_bwd head_fwd head_bwd maxpool > $out/pmc_$n.txt 2>&1
 done
 # the multi-process path of the bench on ONE device (two ranks, gloo transport; RCCL needs >= 2 GPUs): same code above the transport
 HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_DEVICE=0 DD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 3 --batch 32 > $out/two_ranks_one_gpu.txt 2> $out/two_ranks_one_gpu.err
-rm -rf $out/prof $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
+# one rank over RCCL (the nccl backend): communicator, side-stream all-reduces, barriers -- functional record, not a scaling number
+HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $out/one_rank_rccl.txt 2> $out/one_rank_rccl.err
+rm -rf $out/prof $out/prof_inf $out/prof_cfg3 $out/prof_cfg3l $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 cat $out/smoke.txt | tail -2; cut -c1-300 $out/bench.json; cat $out/pmc_*.txt; head -12 $out/kernel_stats.txt
