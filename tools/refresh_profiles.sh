@@ -18,10 +18,10 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_inf -o inf -- python b
 python tools/rocprof_summary.py $(ls $out/prof_inf/*/*results.db $out/prof_inf/*results.db 2>/dev/null | head -1) 40 > $out/inference_kernel_stats.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_cfg3 -o cfg3 -- python tools/cfg3_step.py heavy 8 5 > $out/prof_cfg3.log 2>&1
 python tools/rocprof_summary.py $(ls $out/prof_cfg3/*/*results.db $out/prof_cfg3/*results.db 2>/dev/null | head -1) 40 > $out/cfg3_heavy_kernel_stats.txt 2>&1
-tail -1 $out/prof_cfg3.log >> $out/cfg3_heavy_kernel_stats.txt
+grep "^cfg-3" $out/prof_cfg3.log >> $out/cfg3_heavy_kernel_stats.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_cfg3l -o cfg3l -- python tools/cfg3_step.py light 8 5 > $out/prof_cfg3l.log 2>&1
 python tools/rocprof_summary.py $(ls $out/prof_cfg3l/*/*results.db $out/prof_cfg3l/*results.db 2>/dev/null | head -1) 40 > $out/cfg3_light_kernel_stats.txt 2>&1
-tail -1 $out/prof_cfg3l.log >> $out/cfg3_light_kernel_stats.txt
+grep "^cfg-3" $out/prof_cfg3l.log >> $out/cfg3_light_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $c -d $out/pmc_$n -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-extras --no-graph --steps 2 --warmup 1 > $out/pmc_$n.log 2>&1
