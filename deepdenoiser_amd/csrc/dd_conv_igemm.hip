@@ -900,9 +900,19 @@ static int conv_policy_min_resident_nt() {
 template <typename T>
 int dispatch(ConvP& p, hipStream_t stream) {
   const int tiles_n = p.n_pad / 16;
-  static const int allowed[] = {8, 6, 4, 3, 2, 1};
-  int cands[6], nc = 0;
-  for (int c : allowed) if (tiles_n % c == 0) cands[nc++] = c;
+  // Channel blocks of at most 64 (NT <= 4).  Rounds 1-2 also instantiated NT = 6 and 8; those needed more than the 512-register budget and
+  // spilled 74 ... 159 registers, and measured no faster than two NT = 4 passes (f32 cfg-2 26.04 vs 26.05 ms/step, bf16 heavy Tiramisu 24.15 vs
+  // 24.03 ms/step, round 3), so they are gone.
+  // The last block may be ragged (weight rows past n_pad read as zero, channels past n are not stored): a width is a candidate when the
+  // padding it adds stays under a quarter of the MFMA work (under 40 % for 1x1 layers, which are bound by re-reading the input once per
+  // block: 80 channels = 5 tiles run as 2 blocks of 3 instead of 5 blocks of 1, 176 = 11 tiles as 3 blocks of 4 instead of 11 of 1).
+  static const int allowed[] = {4, 3, 2, 1};
+  int cands[4], nc = 0;
+  for (int c : allowed) {
+    const int nb = (tiles_n + c - 1) / c;
+    if (c == 1 || (nb * c - tiles_n) * (p.taps == 1 ? 5 : 4) <= (p.taps == 1 ? 2 : 1) * tiles_n) cands[nc++] = c;
+  }
+  auto blocks_of = [&](int c) { return (tiles_n + c - 1) / c; };
   const bool halo = p.taps == 9;
   const int nslabs = p.taps * ((p.kchunks + 1) / 2);
   const size_t patch = (size_t)(halo ? (DD_TILE + 2) * (DD_TILE + 2) : DD_TILE * DD_TILE) * DD_LDS_ROW;
@@ -917,12 +927,10 @@ int dispatch(ConvP& p, hipStream_t stream) {
         patch + (ws_ok && cands[i] <= 4 ? (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, cands[i]) + cands[i] * 64
                                          : (size_t)nslabs * cands[i] * 16 * DD_LDS_ROW) <= (ws_ok && cands[i] <= 4 ? (size_t)160 * 1024 : LDS_BUDGET + 2048)) { pick = i; break; }
   // keep every CU busy when the pixel grid is small
-  while (pick + 1 < nc && cands[pick] > 2 && (long)p.total_tiles * (tiles_n / cands[pick]) < 256) ++pick;
+  while (pick + 1 < nc && cands[pick] > 2 && (long)p.total_tiles * blocks_of(cands[pick]) < 256) ++pick;
   const int nt = cands[pick];
-  p.nblk = tiles_n / nt;
+  p.nblk = blocks_of(nt);
   switch (nt) {
-    case 8: return launch_nt<T, 8>(p, stream);
-    case 6: return launch_nt<T, 6>(p, stream);
     case 4: return launch_nt<T, 4>(p, stream);
     case 3: return launch_nt<T, 3>(p, stream);
     case 2: return launch_nt<T, 2>(p, stream);

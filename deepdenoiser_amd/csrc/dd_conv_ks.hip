@@ -36,6 +36,9 @@ constexpr int KS_MAX_SUB = 8;
 struct KsSub { int mode, ct, n0, n_end, nblk, ksplit; };
 struct KsMulti { KsP p; KsSub sub[KS_MAX_SUB]; int in_relu, gather; };
 
+#ifndef KS_DMA_SPAN
+#define KS_DMA_SPAN 8      // eighths of a unit's fragment steps over which the next unit's DMA pieces are issued
+#endif
 typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KS_PW = DD_TILE + 2, KS_PH = DD_TILE + 2, KS_CH = (KS_PW * KS_PH + 7) / 8, KS_BUF = KS_CH * 1024;      // 41 KiB per buffer
 
@@ -176,9 +179,10 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
           if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
           {      // the next unit's DMA pieces and weight fragments, spread evenly over the NF steps: piece k goes with step (k NF) / NPIECE.
                  // (A narrow wave -- 2 output rows, one tap -- has FEWER steps than pieces: several pieces per step, none may be dropped.)
+            constexpr int SPAN = NF * KS_DMA_SPAN / 8 > NPIECE ? NF * KS_DMA_SPAN / 8 : NF;
 #pragma unroll
             for (int k = 0; k < NPIECE; ++k)
-              if ((k * NF) / NPIECE == f) piece(k, nxt, nsl, nbuf);
+              if ((k * SPAN) / NPIECE == f) piece(k, nxt, nsl, nbuf);
 #pragma unroll
             for (int w = 0; w < NWL; ++w)
               if ((w * NF) / NWL == f) wn[w] = load_w(w, nsl);

@@ -210,6 +210,9 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
 // beyond 64 run as further blocks.  This is the data-gradient role of csrc/dd_conv_bwd.hip used as a forward kernel, on all 8 waves.
 // KC = 2: <= 64 input channels, one 64-channel slice, 16 x 16 tiles (18 x 18 haloed: 41 chunks);  KC = 4: <= 128 input channels, two slices,
 // 16 x 8 tiles (18 x 10 haloed: 2 x 23 chunks) -- either way <= 46 KiB per buffer
+#ifndef RW8_DMA_SPAN
+#define RW8_DMA_SPAN 8      // eighths of a tile's fragment steps over which the next tile's DMA pieces are issued (8 = the whole tile)
+#endif
 template <int KC> struct RfGeo {
   static constexpr int NS = (KC + 1) / 2, TH = NS == 1 ? DD_TILE : DD_TILE / 2, PW = DD_TILE + 2, PH = TH + 2;
   static constexpr int CH = (PW * PH + 7) / 8, SLICE = CH * 1024, BUF = NS * SLICE, NCHUNK = NS * CH;
@@ -251,7 +254,11 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       const int pix = c * 8 + rr;
       const int py = (pix * 3641) >> 16, px = pix - py * PW;
       const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = sl * 64 + ls * 8;
+#ifdef RW_EXP_NO_DMA
+      const bool ok = false;      // (knock-out build: every chunk comes from the zero page -- what the kernel costs without its input traffic)
+#else
       const bool ok = t.live && ch < a.cinv && pix < PW * G::PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+#endif
       const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ch) * 2;
       rw_dma_1k(ok ? src : zero, buf + sl * G::SLICE + c * 1024);
     }
@@ -315,7 +322,11 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       o2.x = pack2<T>(v[0], v[1]);
       o2.y = pack2<T>(v[2], v[3]);
       if (a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
+#ifdef RW_EXP_NO_STORE
+      if (col_ok && cur.y0 + half * RH + y < a.H && o2.x == 0x12345678u) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;      // (knock-out build)
+#else
       if (col_ok && cur.y0 + half * RH + y < a.H) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;
+#endif
     };
 #pragma unroll
     for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
@@ -327,9 +338,11 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
         if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
         if (j == 0 && yy < RH) acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
         if (j == 2 && yy >= 3) write_row(yy - 3);
-        {      // the DMA pieces of the next tile, spread evenly over the NF steps
-          const int k0 = (f * NPIECE + NF - 1) / NF;
-          if (k0 < NPIECE && (k0 * NF) / NPIECE == f) piece(k0, nxt, nbuf);
+        {      // the DMA pieces of the next tile, spread evenly over the first RW8_DMA_SPAN / 8 of the NF steps (the rest of the tile hides their latency)
+          constexpr int SPAN = NF * RW8_DMA_SPAN / 8 > NPIECE ? NF * RW8_DMA_SPAN / 8 : NF;
+          static_assert(SPAN >= NPIECE, "at most one piece per step");
+          const int k0 = (f * NPIECE + SPAN - 1) / SPAN;
+          if (k0 < NPIECE && (k0 * SPAN) / NPIECE == f) piece(k0, nxt, nbuf);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
