@@ -23,6 +23,7 @@ SYMBOLS = (
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
     "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_assemble_input", "dd_conv3x3_bwd", "dd_convt2x2_fwd", "dd_convt2x2_bwd", "dd_conv3x3_ks",
+    "dd_conv_pw_count", "dd_wgrad_pw_count",
 )
 
 
@@ -211,6 +212,10 @@ def load():
     lib.dd_convt2x2_fwd.argtypes = [C.POINTER(ConvTArgs), vp]
     lib.dd_convt2x2_bwd.argtypes = [C.POINTER(ConvTArgs), vp]
     lib.dd_conv3x3_ks.argtypes = [C.POINTER(ConvKsArgs), vp]
+    lib.dd_conv_pw_count.argtypes = []
+    lib.dd_conv_pw_count.restype = C.c_long
+    lib.dd_wgrad_pw_count.argtypes = []
+    lib.dd_wgrad_pw_count.restype = C.c_long
     lib.dd_colsum.argtypes = [vp, i, i, l, vp, i, vp]
     lib.dd_maxpool_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, i, vp]
     lib.dd_maxpool_bwd.argtypes = [vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, i, i, vp]

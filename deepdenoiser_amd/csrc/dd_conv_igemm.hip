@@ -942,6 +942,8 @@ int dispatch(ConvP& p, hipStream_t stream) {
 
 bool dd_conv_rw_eligible(const dd_conv_args* a);
 int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream);
+bool dd_conv_pw_eligible(const dd_conv_args* a);
+int dd_conv_pw_launch(const dd_conv_args* a, hipStream_t stream);
 
 extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->x && a->wp && a->y, "dd_conv_igemm: null pointer");
@@ -961,6 +963,8 @@ extern "C" int dd_conv_igemm(const dd_conv_args* a, dd_stream stream) {
   DD_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 16) == 0, "dd_conv_igemm: pointers must be 16-byte aligned");
   // 3x3 layers with 65..96 input channels: weights in registers instead of LDS (csrc/dd_conv_rw.hip)
   if (dd_conv_rw_eligible(a)) return dd_conv_rw_launch(a, reinterpret_cast<hipStream_t>(stream));
+  // wide 1x1 layers: a 256-pixel x 256-channel GEMM tile over the linear pixel index (csrc/dd_conv_pw.hip)
+  if (dd_conv_pw_eligible(a)) return dd_conv_pw_launch(a, reinterpret_cast<hipStream_t>(stream));
 
   ConvP p;
   p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.res = a->res; p.mask = a->mask; p.y = a->y;

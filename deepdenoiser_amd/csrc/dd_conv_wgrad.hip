@@ -743,6 +743,9 @@ int dispatch(const WgradP& p, hipStream_t stream) {
 
 }  // namespace
 
+bool dd_wgrad_pw_eligible(const dd_wgrad_args* a);
+int dd_wgrad_pw_launch(const dd_wgrad_args* a, hipStream_t stream);
+
 extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->p && a->q && a->out, "dd_conv_wgrad: null pointer");
   DD_REQUIRE(dd_dtype_ok(a->dtype), "dd_conv_wgrad: bad dtype %d", a->dtype);
@@ -756,6 +759,8 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "dd_conv_wgrad: empty grid");
   DD_REQUIRE(((uintptr_t)a->p % 16) == 0 && ((uintptr_t)a->q % 16) == 0, "dd_conv_wgrad: pointers must be 16-byte aligned");
   DD_REQUIRE(a->bias_mode >= 0 && a->bias_mode <= 2 && (a->bias_mode == 0 || a->bias_out), "dd_conv_wgrad: bias_mode=%d needs bias_out", a->bias_mode);
+  // wide 1x1 layers: the gradient as 256 x 256 GEMM tiles over the linear pixel index (csrc/dd_conv_pw.hip)
+  if (dd_wgrad_pw_eligible(a)) return dd_wgrad_pw_launch(a, reinterpret_cast<hipStream_t>(stream));
   WgradP p;
   p.p = a->p; p.q = a->q; p.out = a->out; p.bias_out = a->bias_out; p.bias_mode = a->bias_mode;
   p.ldp = a->ldp; p.m = a->m; p.ldq = a->ldq; p.n = a->n; p.mv = mv; p.nv = nv;

@@ -77,6 +77,11 @@ typedef struct {
   int taps; int flags; int dtype;
 } dd_conv_args;
 int dd_conv_igemm(const dd_conv_args* a, dd_stream stream);
+/* Number of dd_conv_igemm calls this process routed to the wide 1x1 GEMM kernel (csrc/dd_conv_pw.hip: taps == 1, 2-byte storage, more than
+ * 64 output channels, no residual operand, at least DD_CONV_PW_MIN_PIXELS = 32 768 pixels; DD_CONV_PW=0 turns the route off).  Tests use it
+ * to assert that the kernel they mean to check is the one that ran. */
+long dd_conv_pw_count(void);
+long dd_wgrad_pw_count(void);   /* ... and dd_conv_wgrad calls routed to its weight-gradient counterpart (taps == 1, m or n above 64 channels) */
 
 /* ---- weight gradient on MFMA: out[t][m][n] += sum_{b,p} in(P)[b,map_t(p),m] * Q[b,p,n]   (fp32 atomics)
  * conv2d:            P = layer input x, Q = pre-activation output gradient -> out = dKernel HWIO

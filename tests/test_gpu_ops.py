@@ -201,6 +201,30 @@ def test_conv_over_skip_concat_runs_as_two_resident_launches(eng, dtype, cin, co
     _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, split_at=split_at)
 
 
+# the wide 1x1 GEMM kernel (csrc/dd_conv_pw.hip): Tiramisu's transition convs (C -> C over the whole concat, pre-activation) and the data gradients
+# of the head's 1x1 convs (25 -> C with the consumer's ReLU mask); one to three channel blocks, ragged last pixel tile, one to eleven K-slices
+PW_CASES = [
+    # cin, cout, H, W, B, relu, in_relu, x_relu, pw launches expected (forward, data gradient, weight gradient)
+    (80, 80, 128, 128, 2, False, True, False, 1, 1, 1),
+    (176, 176, 64, 64, 8, True, False, True, 1, 1, 0),      # mid-sized weight gradient: stays on the 64 x 64-slice kernel (fewer atomics)
+    (320, 320, 100, 100, 4, False, True, False, 1, 1, 1),
+    (704, 704, 96, 128, 3, False, True, False, 1, 1, 1),
+    (160, 25, 256, 128, 1, False, False, True, 0, 1, 1),   # forward on the igemm kernel (32 padded output channels), data gradient 25 -> 160 here
+    (296, 24, 128, 130, 2, False, True, False, 0, 1, 1),
+    (640, 160, 64, 64, 8, True, False, False, 1, 1, 1),
+    (100, 84, 181, 200, 1, True, True, False, 1, 1, 1),    # channel counts that end inside a 16-byte group, ragged last pixel tile
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,B,relu,in_relu,x_relu,nf,nb,nw", PW_CASES)
+def test_conv_1x1_wide_gemm(lib, eng, dtype, cin, cout, H, W, B, relu, in_relu, x_relu, nf, nb, nw):
+    before, wbefore = lib.dd_conv_pw_count(), lib.dd_wgrad_pw_count()
+    _conv_case(eng, dtype, 1, cin, cout, H, W, relu, in_relu, False, x_relu, B=B)
+    assert lib.dd_conv_pw_count() - before == nf + nb, "the wide 1x1 kernel did not take the launches it was expected to"
+    assert lib.dd_wgrad_pw_count() - wbefore == nw, "the 1x1 weight-gradient GEMM did not take the launch it was expected to"
+
+
 def _conv_case(eng, dtype, k, cin, cout, H, W, relu, in_relu, residual, x_relu, B, split_at=None, expect_fused_bwd=False, x_requires_grad=True,
                expect_fwd_tag=None):
     gen = _gen(k * 1000 + cin + cout)
