@@ -25,7 +25,7 @@ grep "^cfg-3" $out/prof_cfg3l.log >> $out/cfg3_light_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $c -d $out/pmc_$n -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-extras --no-graph --steps 2 --warmup 1 > $out/pmc_$n.log 2>&1
-  python tools/pmc_family.py $out/pmc_$n conv_igemm conv_rw conv_ks wgrad_dma conv_bwd convt_fwd convt_bwd compose_fwd compose_bwd head_fwd head_bwd maxpool > $out/pmc_$n.txt 2>&1
+  python tools/pmc_family.py $out/pmc_$n conv_igemm conv_rw conv_ks conv_pw wgrad_pw wgrad_dma conv_bwd convt_fwd convt_bwd compose_fwd compose_bwd head_fwd head_bwd maxpool > $out/pmc_$n.txt 2>&1
 done
 # the multi-process path of the bench on ONE device (two ranks, gloo transport; RCCL needs >= 2 GPUs): same code above the transport
 HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_DEVICE=0 DD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 3 --batch 32 > $out/two_ranks_one_gpu.txt 2> $out/two_ranks_one_gpu.err
