@@ -28,7 +28,7 @@ struct KsP {
   const void* x; const void* wp; const float* bias; const void* mask; void* y;
   int ldx, ldy, ldmask, cinv, n_end, n0, n_pad, k_pad, nbias, nslices;
   int B, H, W, tiles_x, tiles_y, nblk, ksplit;
-  int relu, out_mul, out_py, out_px, Hout, Wout;
+  int relu, accum, out_mul, out_py, out_px, Hout, Wout;
 };
 // One launch = up to KS_MAX_SUB sub-problems over the same input and weight image (blockIdx.y picks one): the channel blocks of a layer (96 output
 // channels = 64 + 32) and the four output parities of a transposed conv run side by side instead of as 2 ... 8 launches of a few dozen workgroups.
@@ -55,9 +55,11 @@ struct KsTile { int b, y0, x0; bool live; };
 // taps of one axis: P = -1 all three (plain conv); P = 0 / 1: the taps of output parity P of the stride-2 transposed conv.  Tap t reads the input at
 // offset t - 1.  In the packed image of the zero-stuffed form (flipped kernel: image tap u = K[2 - u]) parity 0 uses image taps 0 and 2 at input
 // offsets -1 and 0 (kernel taps t = 0, 1 here), parity 1 image tap 1 at offset 0 (t = 1).
-constexpr int ks_t0(int p) { return p == 1 ? 1 : 0; }
-constexpr int ks_t1(int p) { return p < 0 ? 2 : 1; }
-constexpr int ks_src(int p, int t) { return p < 0 ? t : (p == 0 ? (t == 0 ? 0 : 2) : 1); }
+// P = 2 (MODE 6): taps 1 and 2 (input offsets 0 and +1) of the image as it is: the 2 x 2-tap conv over a space-to-depth tensor that is the data
+// gradient of the transposed conv (see dd_conv3x3_ks mode 6).
+constexpr int ks_t0(int p) { return p >= 1 ? 1 : 0; }
+constexpr int ks_t1(int p) { return (p < 0 || p == 2) ? 2 : 1; }
+constexpr int ks_src(int p, int t) { return (p < 0 || p == 2) ? t : (p == 0 ? (t == 0 ? 0 : 2) : 1); }
 
 // GATHER (mode 0 only): the epilogue of a data gradient in gather form -- y = y + (mask > 0 ? sum : 0), no bias, no activation: the gradient of
 // a channel range of a dense-block buffer from ALL the later convs of the block at once (their output gradients are one contiguous channel range =
@@ -66,7 +68,7 @@ template <typename T, int CT, int MODE, bool IN_RELU, bool GATHER = false>
 __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block) {
   static_assert(sizeof(T) == 2, "K-streamed conv: bf16 / fp16 storage");
   static_assert(CT == 1 || CT == 2 || CT == 4, "1, 2 or 4 output-channel tiles per workgroup");
-  constexpr int PY = MODE == 0 ? -1 : (MODE - 1) >> 1, PX = MODE == 0 ? -1 : (MODE - 1) & 1;
+  constexpr int PY = MODE == 0 ? -1 : MODE == 6 ? 2 : (MODE - 1) >> 1, PX = MODE == 0 ? -1 : MODE == 6 ? 2 : (MODE - 1) & 1;
   constexpr int TY0 = ks_t0(PY), NTY = ks_t1(PY) - TY0 + 1, TX0 = ks_t0(PX), NTX = ks_t1(PX) - TX0 + 1;
   constexpr int RG = 8 / CT, RH = DD_TILE / RG;       // row groups per tile; output rows per wave
   constexpr int NYY = RH + NTY - 1;                   // haloed rows a wave reads (TY0 .. TY0 + NYY - 1 of its band)
@@ -201,7 +203,8 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
         const bool col_ok = ch_ok && cur.x0 + li < a.W;
         const int oy0 = (cur.y0 + half * RH) * a.out_mul + a.out_py, ox = (cur.x0 + li) * a.out_mul + a.out_px;
         T* yp = Y + (((long)cur.b * a.Hout + oy0) * a.Wout + ox) * a.ldy + c4;
-        if (GATHER) {
+        if (GATHER) {      // y = (accumulate ? y : 0) + (mask ? (mask > 0 ? sum : 0) : sum), rounded once
+          const bool has_mask = a.mask != nullptr;
           const T* mp = reinterpret_cast<const T*>(a.mask) + (((long)cur.b * a.H + cur.y0 + half * RH) * a.W + cur.x0 + li) * a.ldmask + c4;
           const long mrow = (long)a.W * a.ldmask;
           constexpr int GB = RH < 4 ? RH : 4;      // rows per batch: their loads first (one exposed round trip per batch), then the arithmetic
@@ -211,8 +214,8 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
 #pragma unroll
             for (int y = 0; y < GB; ++y) {
               const bool ok = col_ok && cur.y0 + half * RH + yb + y < a.H;
-              mv[y] = ok ? *reinterpret_cast<const uint2*>(mp + (yb + y) * mrow) : uint2{0u, 0u};
-              ov[y] = ok ? *reinterpret_cast<const uint2*>(yp + (yb + y) * yrow) : uint2{0u, 0u};
+              mv[y] = (ok && has_mask) ? *reinterpret_cast<const uint2*>(mp + (yb + y) * mrow) : uint2{0u, 0u};
+              ov[y] = (ok && a.accum) ? *reinterpret_cast<const uint2*>(yp + (yb + y) * yrow) : uint2{0u, 0u};
             }
 #pragma unroll
             for (int y = 0; y < GB; ++y) {
@@ -221,8 +224,8 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
               unpack8t<T>(uint4{ov[y].x, ov[y].y, 0u, 0u}, o8);
               const f32x4_t v = acc[yb + y];
               uint2 o2;
-              o2.x = pack2<T>(o8[0] + (m8[0] > 0.f ? v[0] : 0.f), o8[1] + (m8[1] > 0.f ? v[1] : 0.f));
-              o2.y = pack2<T>(o8[2] + (m8[2] > 0.f ? v[2] : 0.f), o8[3] + (m8[3] > 0.f ? v[3] : 0.f));
+              o2.x = pack2<T>(o8[0] + ((!has_mask || m8[0] > 0.f) ? v[0] : 0.f), o8[1] + ((!has_mask || m8[1] > 0.f) ? v[1] : 0.f));
+              o2.y = pack2<T>(o8[2] + ((!has_mask || m8[2] > 0.f) ? v[2] : 0.f), o8[3] + ((!has_mask || m8[3] > 0.f) ? v[3] : 0.f));
               if (col_ok && cur.y0 + half * RH + yb + y < a.H) *reinterpret_cast<uint2*>(yp + (yb + y) * yrow) = o2;
             }
           }
@@ -260,7 +263,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const KsMulti m) {
   if ((int)blockIdx.x >= sb.nblk * sb.ksplit) return;      // (whole workgroup: no barrier is skipped by part of it)
   KsP a = m.p;
   a.n0 = sb.n0; a.n_end = sb.n_end; a.nblk = sb.nblk; a.ksplit = sb.ksplit;
-  a.out_mul = sb.mode == 0 ? 1 : 2; a.out_py = sb.mode == 0 ? 0 : (sb.mode - 1) >> 1; a.out_px = sb.mode == 0 ? 0 : (sb.mode - 1) & 1;
+  const bool plain = sb.mode == 0 || sb.mode == 6;      // output on the input grid
+  a.out_mul = plain ? 1 : 2; a.out_py = plain ? 0 : (sb.mode - 1) >> 1; a.out_px = plain ? 0 : (sb.mode - 1) & 1;
   a.Hout = a.H * a.out_mul; a.Wout = a.W * a.out_mul;
   const int b = blockIdx.x;
 #define KS_CASE(CT_, MODE_, RELU_) conv_ks_body<T, CT_, MODE_, RELU_>(a, smem, b)
@@ -271,7 +275,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const KsMulti m) {
     case 1: KS_CASE(CT_, 1, false); break;                                 \
     case 2: KS_CASE(CT_, 2, false); break;                                 \
     case 3: KS_CASE(CT_, 3, false); break;                                 \
-    default: KS_CASE(CT_, 4, false); break;                                \
+    case 4: KS_CASE(CT_, 4, false); break;                                 \
+    default: if (m.gather) conv_ks_body<T, CT_, 6, false, true>(a, smem, b); else KS_CASE(CT_, 6, false); break; \
   }
   if (sb.ct == 4) { KS_MODES(4) } else if (sb.ct == 2) { KS_MODES(2) } else { KS_MODES(1) }
 #undef KS_MODES
@@ -294,12 +299,13 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->x && a->wp && a->y, "dd_conv3x3_ks: null pointer");
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_ks: storage dtype must be DD_BF16 or DD_F16");
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->cin > 0 && a->n > 0 && a->n0 >= 0, "dd_conv3x3_ks: empty problem");
-  DD_REQUIRE(a->mode >= 0 && a->mode <= 5, "dd_conv3x3_ks: mode %d (0: 3x3 SAME conv; 1..4: output parity (py, px) = ((mode-1)/2, (mode-1)%%2) of the 3x3/s2 transposed conv; 5: all four)", a->mode);
-  DD_REQUIRE(a->mode == 0 || !(a->flags & DD_IN_RELU), "dd_conv3x3_ks: the transposed conv takes no input ReLU");
+  DD_REQUIRE(a->mode >= 0 && a->mode <= 6, "dd_conv3x3_ks: mode %d (0: 3x3 SAME conv; 1..4: output parity (py, px) = ((mode-1)/2, (mode-1)%%2) of the 3x3/s2 transposed conv; 5: all four; 6: image taps (1..2, 1..2) at offsets 0 / +1)", a->mode);
+  DD_REQUIRE(a->mode == 0 || !(a->flags & DD_IN_RELU), "dd_conv3x3_ks: only mode 0 takes an input ReLU");
   DD_REQUIRE((a->flags & ~(DD_IN_RELU | DD_OUT_RELU | DD_ACCUM)) == 0, "dd_conv3x3_ks: flags %d unsupported (DD_IN_RELU | DD_OUT_RELU | DD_ACCUM)", a->flags);
-  const bool gather = (a->flags & DD_ACCUM) != 0;
-  DD_REQUIRE(!gather || (a->mode == 0 && a->mask && !(a->flags & (DD_IN_RELU | DD_OUT_RELU)) && a->ldmask % 4 == 0 && ((uintptr_t)a->mask % 8) == 0),
-             "dd_conv3x3_ks: DD_ACCUM is the gather-form data gradient: mode 0, a mask tensor (8-byte aligned, ldmask %% 4 == 0), no ReLU flags");
+  // gradient epilogue (no bias, no activation): DD_ACCUM and / or a mask tensor
+  const bool gather = (a->flags & DD_ACCUM) != 0 || a->mask != nullptr;
+  DD_REQUIRE(!gather || ((a->mode == 0 || a->mode == 6) && !(a->flags & (DD_IN_RELU | DD_OUT_RELU)) && (!a->mask || (a->ldmask % 4 == 0 && ((uintptr_t)a->mask % 8) == 0))),
+             "dd_conv3x3_ks: the gradient epilogue (DD_ACCUM and / or a mask): mode 0 or 6, mask 8-byte aligned with ldmask %% 4 == 0, no ReLU flags");
   DD_REQUIRE(a->ldx % 8 == 0 && a->ldy % 4 == 0 && a->k_pad % 32 == 0 && a->n_pad % 16 == 0 && a->n0 % 16 == 0 && a->n % 4 == 0,
              "dd_conv3x3_ks: ldx=%d (%%8) ldy=%d (%%4) k_pad=%d (%%32) n_pad=%d (%%16) n0=%d (%%16) n=%d (%%4)", a->ldx, a->ldy, a->k_pad, a->n_pad, a->n0, a->n);
   DD_REQUIRE(a->n0 + a->n <= a->n_pad && a->cin <= a->k_pad, "dd_conv3x3_ks: channel ranges exceed the packed weight image");
@@ -310,7 +316,7 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldmask = a->ldmask; p.cinv = (a->cin + 7) / 8 * 8; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
   p.nbias = a->nbias; p.nslices = (a->cin + 63) / 64;
   p.B = a->B; p.H = a->H; p.W = a->W;
-  p.relu = (a->flags & DD_OUT_RELU) != 0;
+  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
   p.n0 = p.n_end = p.nblk = p.ksplit = p.out_mul = p.out_py = p.out_px = p.Hout = p.Wout = 0;      // per sub-problem, set by the kernel
   m.in_relu = (a->flags & DD_IN_RELU) != 0;

@@ -316,6 +316,7 @@ struct PwgP {
   int ldp, ldq, m, n, mv, nv, bias_mode, in_relu;
   long M;
   int nunits, mblk, nblk, spx;      // 64-pixel units; tile grid of the gradient; pixel splits per XCD
+  int g9_cp, g9_cout, g9_H, g9_W;   // G9 (transposed-conv filter gradient): channel pitch of a parity plane, real output channels, input grid
 };
 
 // LDS image of the weight-gradient kernel: pixel rows of 128 B whose 16-byte slots are XOR-swizzled with key(p) = 2 * (p & 3).  A transposing
@@ -333,7 +334,10 @@ __device__ __forceinline__ uint4 pw_tr_pair(unsigned lo_addr) {
   return v;
 }
 
-template <typename T, int CTM, int CTN>
+// G9: the filter gradient of the 3x3 / stride-2 transposed conv (dd_convt3_wgrad).  P is the space-to-depth output gradient; row m of the GEMM is
+// (tap (a, b) = m / cp, output channel co = m % cp) and reads s at pixel offset ((a == 2), (b == 2)), channels plane(a, b)*cp + co -- nine shifted
+// channel windows of one tensor, gathered by the DMA address of each 8-channel group; the result goes to dK[a][b][co][ci].
+template <typename T, int CTM, int CTN, bool G9 = false>
 __global__ __launch_bounds__(512) void wgrad_pw_kernel(const PwgP a) {
   static_assert(sizeof(T) == 2, "1x1 weight gradient GEMM: bf16 / fp16 storage");
   static_assert(CTM * CTN <= 32, "at most 128 accumulator registers per wave");
@@ -356,13 +360,35 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(const PwgP a) {
   const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
   const char* P = reinterpret_cast<const char*>(a.p);
   const char* Q = reinterpret_cast<const char*>(a.q);
+  // G9: per 64-row slice, this lane's 8 rows belong to one tap: its pixel offset (rows, columns), and the element offset of its source window
+  int g_dy[CSM], g_dx[CSM], g_off[CSM];
+  if constexpr (G9) {
+#pragma unroll
+    for (int cs = 0; cs < CSM; ++cs) {
+      const int ch = mb * MB + cs * 64 + ls * 8, tap = ch / a.g9_cp, co = ch - tap * a.g9_cp;
+      const int ta = tap / 3, tb = tap - ta * 3;
+      g_dy[cs] = tap < 9 ? (ta == 2) : a.g9_H;      // rows past the ninth tap: always out of range
+      g_dx[cs] = tb == 2;
+      g_off[cs] = ((ta == 2) * a.g9_W + (tb == 2)) * a.ldp + ((ta & 1) * 2 + (tb & 1)) * a.g9_cp + co;
+    }
+  }
   auto dma = [&](int u, unsigned buf) {      // unit u: pixels u*64 + wave*8 + r, every 64-channel slice of both blocks
     const long pix = (long)u * 64 + wave * 8 + pw_opaque(r);
     const bool pix_ok = pix < a.M;
+    int gi = 0, gj = 0;
+    if constexpr (G9) {
+      const unsigned up = (unsigned)pix, row = up / (unsigned)a.g9_W;      // (M < 2^31: checked by the host)
+      gj = (int)(up - row * (unsigned)a.g9_W); gi = (int)(row % (unsigned)a.g9_H);
+    }
 #pragma unroll
     for (int cs = 0; cs < CSM; ++cs) {
-      const int ch = mb * MB + cs * 64 + ls * 8;
-      pw_dma_1k((pix_ok && ch < a.mv) ? P + (pix * a.ldp + ch) * 2 : zero, buf + cs * CS_BYTES + wave * 1024);
+      if constexpr (G9) {
+        const bool ok = pix_ok && gi + g_dy[cs] < a.g9_H && gj + g_dx[cs] < a.g9_W;
+        pw_dma_1k(ok ? P + (pix * a.ldp + g_off[cs]) * 2 : zero, buf + cs * CS_BYTES + wave * 1024);
+      } else {
+        const int ch = mb * MB + cs * 64 + ls * 8;
+        pw_dma_1k((pix_ok && ch < a.mv) ? P + (pix * a.ldp + ch) * 2 : zero, buf + cs * CS_BYTES + wave * 1024);
+      }
     }
 #pragma unroll
     for (int cs = 0; cs < CSN; ++cs) {
@@ -444,6 +470,11 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(const PwgP a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int m = mb * MB + (wm * CTM + i) * 16 + q4 + e;
+          if constexpr (G9) {
+            const int tap = m / a.g9_cp, co = m - tap * a.g9_cp;
+            if (tap < 9 && co < a.g9_cout) atomicAdd(a.out + ((long)tap * a.g9_cout + co) * a.n + n, acc[i][jn][e]);
+            continue;
+          }
 #ifdef PWG_EXP_NO_ATOMIC
           if (m < a.m && acc[i][jn][e] == 12345.f) a.out[(long)m * a.n + n] = 1.f;
 #else
@@ -470,9 +501,15 @@ constexpr PwgCfg PWG_CFGS[] = {{4, 8}, {5, 5}, {3, 6}, {2, 3}, {5, 1}, {5, 2}, {
 template <typename T, int CTM, int CTN>
 void wgrad_pw_launch_cfg(const PwgP& p, unsigned grid, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(CTM + (CTN + 1) / 2) * 64 * DD_LDS_ROW;
+  if (p.g9_cp) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    hipLaunchKernelGGL((wgrad_pw_kernel<T, CTM, CTN, true>), dim3(grid), dim3(512), lds, s, p);
+    return;
+  }
   static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-  hipLaunchKernelGGL((wgrad_pw_kernel<T, CTM, CTN>), dim3(grid), dim3(512), lds, s, p);
+  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+  hipLaunchKernelGGL((wgrad_pw_kernel<T, CTM, CTN, false>), dim3(grid), dim3(512), lds, s, p);
 }
 
 template <typename T>
@@ -543,22 +580,16 @@ bool dd_wgrad_pw_eligible(const dd_wgrad_args* a) {
 static long g_pwg_launches = 0;
 extern "C" long dd_wgrad_pw_count(void) { return g_pwg_launches; }
 
-int dd_wgrad_pw_launch(const dd_wgrad_args* a, hipStream_t s) {
-  ++g_pwg_launches;
-  PwgP p;
-  p.p = a->p; p.q = a->q; p.out = a->out; p.bias_out = a->bias_out; p.bias_mode = a->bias_mode;
-  p.ldp = a->ldp; p.ldq = a->ldq; p.m = a->m; p.n = a->n; p.mv = (a->m + 7) / 8 * 8; p.nv = (a->n + 7) / 8 * 8;
-  p.in_relu = (a->flags & DD_IN_RELU) != 0;
-  p.M = (long)a->B * a->H * a->W;
-  p.nunits = (int)((p.M + 63) / 64);
+// tile shape and pixel splits for an m x n gradient over p.nunits units; launches
+static int pwg_plan_and_launch(PwgP& p, int dtype, hipStream_t s) {
   // tile shape: the candidate with the least (operand re-reads + padded MFMA work), both in seconds per pixel at 4 TB/s and 1.2 PFLOP/s
-  const int nmt = (a->m + 15) / 16, nnt = (a->n + 15) / 16;
+  const int nmt = (p.m + 15) / 16, nnt = (p.n + 15) / 16;
   int best = 0;
   double best_cost = 1e30;
   for (int c = 0; c < (int)(sizeof(PWG_CFGS) / sizeof(PWG_CFGS[0])); ++c) {
     const int mt = 4 * PWG_CFGS[c].ctm, nt = 2 * PWG_CFGS[c].ctn;
     const int mblk = (nmt + mt - 1) / mt, nblk = (nnt + nt - 1) / nt;
-    const double bytes = 2.0 * ((double)nblk * a->m + (double)mblk * a->n), flops = 2.0 * (mblk * mt * 16.0) * (nblk * nt * 16.0);
+    const double bytes = 2.0 * ((double)nblk * p.m + (double)mblk * p.n), flops = 2.0 * (mblk * mt * 16.0) * (nblk * nt * 16.0);
     const double cost = bytes / 4e12 + flops / 1.2e15;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
@@ -571,8 +602,38 @@ int dd_wgrad_pw_launch(const dd_wgrad_args* a, hipStream_t s) {
   while (spx > 1 && (long)spx * 8 > p.nunits) --spx;
   p.spx = spx;
   const unsigned grid = (unsigned)(8 * spx * ntp);
-  if (a->dtype == DD_BF16) wgrad_pw_launch<bf16_t>(p, best, grid, s);
+  if (dtype == DD_BF16) wgrad_pw_launch<bf16_t>(p, best, grid, s);
   else wgrad_pw_launch<f16_t>(p, best, grid, s);
   DD_LAUNCH_CHECK();
   return DD_OK;
+}
+
+int dd_wgrad_pw_launch(const dd_wgrad_args* a, hipStream_t s) {
+  ++g_pwg_launches;
+  PwgP p;
+  p.p = a->p; p.q = a->q; p.out = a->out; p.bias_out = a->bias_out; p.bias_mode = a->bias_mode;
+  p.ldp = a->ldp; p.ldq = a->ldq; p.m = a->m; p.n = a->n; p.mv = (a->m + 7) / 8 * 8; p.nv = (a->n + 7) / 8 * 8;
+  p.in_relu = (a->flags & DD_IN_RELU) != 0;
+  p.M = (long)a->B * a->H * a->W;
+  p.nunits = (int)((p.M + 63) / 64);
+  p.g9_cp = p.g9_cout = p.g9_H = p.g9_W = 0;
+  return pwg_plan_and_launch(p, a->dtype, s);
+}
+
+extern "C" int dd_convt3_wgrad(const dd_convt3_wgrad_args* a, dd_stream stream) {
+  DD_REQUIRE(a && a->s && a->x && a->dk, "dd_convt3_wgrad: null pointer");
+  DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_convt3_wgrad: storage dtype must be DD_BF16 or DD_F16");
+  DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->cin > 0 && a->cout > 0, "dd_convt3_wgrad: empty problem");
+  DD_REQUIRE(a->cp % 16 == 0 && a->cp >= a->cout && a->lds % 8 == 0 && a->lds >= 4 * a->cp && a->ldx % 8 == 0 && a->ldx >= (a->cin + 7) / 8 * 8,
+             "dd_convt3_wgrad: cp=%d (%%16, >= cout=%d) lds=%d (%%8, >= 4 cp) ldx=%d (%%8, covers cin=%d rounded to 8)", a->cp, a->cout, a->lds, a->ldx, a->cin);
+  DD_REQUIRE(((uintptr_t)a->s % 16) == 0 && ((uintptr_t)a->x % 16) == 0, "dd_convt3_wgrad: s / x must be 16-byte aligned");
+  PwgP p;
+  p.p = a->s; p.q = a->x; p.out = a->dk; p.bias_out = nullptr; p.bias_mode = 0;
+  p.ldp = a->lds; p.ldq = a->ldx; p.m = 9 * a->cp; p.n = a->cin; p.mv = p.m; p.nv = (a->cin + 7) / 8 * 8;
+  p.in_relu = 0;
+  p.M = (long)a->B * a->H * a->W;
+  p.nunits = (int)((p.M + 63) / 64);
+  p.g9_cp = a->cp; p.g9_cout = a->cout; p.g9_H = a->H; p.g9_W = a->W;
+  DD_REQUIRE(p.M < (1L << 31), "dd_convt3_wgrad: more than 2^31 pixels");
+  return pwg_plan_and_launch(p, a->dtype, reinterpret_cast<hipStream_t>(stream));
 }

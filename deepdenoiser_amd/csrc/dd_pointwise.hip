@@ -1342,6 +1342,37 @@ extern "C" int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, in
   return DD_OK;
 }
 
+// Space-to-depth of a fine-grid tensor (2H x 2W) by output parity: s[b][i][j][(py*2 + px)*cp + c] = y[b][2i + py][2j + px][c] for c < C, zero for
+// C <= c < cp.  One thread = 4 channels of one plane of one coarse pixel.
+template <typename T>
+__global__ void space_to_depth2_kernel(const T* __restrict__ y, int ldy, T* __restrict__ s, int lds, int C, int cp, int B, int H, int W) {
+  const int cg = cp >> 2;
+  const long total = (long)B * H * W * 4 * cg;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * 4;
+  long r = i / cg;
+  const int plane = (int)(r & 3); r >>= 2;
+  const int x = (int)(r % W); r /= W;
+  const int yy = (int)(r % H);
+  const int b = (int)(r / H);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    load4<T>(y + (((long)b * 2 * H + 2 * yy + (plane >> 1)) * 2 * W + 2 * x + (plane & 1)) * ldy + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (c + e >= C) v[e] = 0.f;
+  }
+  store4<T>(s + (((long)b * H + yy) * W + x) * lds + plane * cp + c, v);
+}
+extern "C" int dd_space_to_depth2(const void* y, int ldy, void* s, int lds, int C, int cp, int B, int H, int W, int dtype, dd_stream stream) {
+  DD_REQUIRE(y && s && C > 0 && cp >= C && cp % 4 == 0 && ldy % 4 == 0 && lds % 4 == 0 && lds >= 4 * cp && ldy >= (C + 3) / 4 * 4,
+             "dd_space_to_depth2: C=%d cp=%d ldy=%d lds=%d (cp, ld multiples of 4; lds >= 4 cp; the 4-channel group holding channel C - 1 readable)", C, cp, ldy, lds);
+  const long total = (long)B * H * W * cp;
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(space_to_depth2_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)y, ldy, (T*)s, lds, C, cp, B, H, W));
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
 template <typename T>
 __global__ void zero_unstuff_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, const T* __restrict__ mask, int ldmask,
                                     int C, int B, int H, int W, int accumulate) {

@@ -640,8 +640,24 @@ class Graph:
         # csrc/dd_conv_ks.hip modes 1..4); the backward still differentiates the zero-stuffed form, so a training graph keeps the stuffed copy
         parity = (self.dtype in ("bf16", "f16") and layer.cout % 4 == 0 and layer.cout <= 128 and x.ld % 8 == 0 and y.ld % 4 == 0 and x.ch0 % 8 == 0 and y.ch0 % 4 == 0
                   and os.environ.get("DD_CONVT3_PARITY", "1") != "0")
-        need_z = (not parity) or bool(getattr(self, "training", True))
+        # ... and so does the BACKWARD (round 3): with the output gradient rearranged by output parity (dd_space_to_depth2) the data gradient is a
+        # 2 x 2-tap conv on the input grid (dd_conv3x3_ks mode 6) and the filter gradient one GEMM over nine shifted channel windows
+        # (dd_convt3_wgrad): no zero-stuffed tensor, no 4x-redundant MACs.  DD_CONVT3_S2D_BWD=0: differentiate the zero-stuffed form instead.
+        s2d_bwd = (parity and x.ld % 8 == 0 and x.ch0 % 8 == 0 and layer.cin % 4 == 0 and os.environ.get("DD_CONVT3_S2D_BWD", "1") != "0")
+        need_z = (not parity) or (bool(getattr(self, "training", True)) and not s2d_bwd)
         z = self.tensor(x.B, 2 * x.H, 2 * x.W, x.C, requires_grad=x.requires_grad) if need_z else None
+        if s2d_bwd:
+            # data-gradient operand [9][cin][4 cp]: image tap (1 + (a == 2), 1 + (b == 2)), column block plane(a, b) = K[a][b][:, :] transposed
+            cp = round_up(layer.cout, 16)
+            s2d_n_pad, s2d_k_pad = round_up(layer.cin, 16), round_up(4 * cp, 64 // _ESZ[self.dtype])
+            s2d_img = torch.zeros(9 * s2d_n_pad * s2d_k_pad, dtype=_TORCH_DT[self.dtype], device=self.device)
+            for ta in range(3):
+                for tb in range(3):
+                    tap_img = (1 + (ta == 2)) * 3 + (1 + (tb == 2))
+                    plane = (ta & 1) * 2 + (tb & 1)
+                    self.register_pack(layer.kernel, s2d_img, 1, layer.cin, layer.cout, s2d_n_pad, cp, 0, 1, layer.cin, 0,
+                                       src_offset=(ta * 3 + tb) * layer.cout * layer.cin,
+                                       dst_offset=tap_img * s2d_n_pad * s2d_k_pad + plane * cp, dst_ld=s2d_k_pad, dst_tap_stride=s2d_n_pad * s2d_k_pad)
         if need_z:
             def stuff(stream):
                 L.check(lib.dd_zero_stuff(x.ptr, x.ld, z.ptr, z.ld, x.Cp, x.B, x.H, x.W, code, stream))
@@ -661,9 +677,56 @@ class Graph:
             self.fwd(self._defer(lambda: self._conv_call(z, wp, taps, n_pad, k_pad, ps.value_ptr(layer.bias), layer.cout, None, None, y,
                                                          z.B, z.H, z.W, L.OUT_RELU if relu else 0, nk=(layer.cout, layer.cin)), "conv_igemm"))
 
+        def backward_s2d():
+            gy = y.grad()
+            self._self_mask(y, gy)
+            sd = self.tensor(x.B, x.H, x.W, 4 * cp, requires_grad=False)      # the output gradient by output parity
+            es = _ESZ[self.dtype]
+
+            def s2d(stream):
+                L.check(lib.dd_space_to_depth2(gy.ptr, gy.ld, sd.ptr, sd.ld, layer.cout, cp, x.B, x.H, x.W, code, stream))
+            self.bwd(s2d)
+            self.bwd(self._bias_grad_call(gy, layer.cout, layer.bias), grad_params=[layer.bias])
+            wrec = {"flops": 2.0 * x.B * x.H * x.W * 9 * layer.cin * layer.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "n": layer.cin, "k": layer.cout}
+            self.wgrad_records.append(wrec)
+
+            def convt3_wgrad(stream, cell=[]):
+                if not cell:      # (pointers into the parameter arena exist once the graph is finalised)
+                    wa = L.ConvT3WgradArgs()
+                    wa.s, wa.lds, wa.cout, wa.cp = sd.ptr, sd.ld, layer.cout, cp
+                    wa.x, wa.ldx, wa.cin = x.ptr, x.ld, layer.cin
+                    wa.dk = ps.grad_ptr(layer.kernel)
+                    wa.B, wa.H, wa.W, wa.dtype = x.B, x.H, x.W, code
+                    cell.append(wa)
+                L.check(lib.dd_convt3_wgrad(C.byref(cell[0]), stream))
+            convt3_wgrad.tag, convt3_wgrad.info = "conv_wgrad", wrec
+            self.bwd(convt3_wgrad, grad_params=[layer.kernel])
+            if x.requires_grad:
+                gx = x.grad()
+                rec = {"flops": 2.0 * x.B * x.H * x.W * 9 * layer.cin * layer.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "n": layer.cin, "k": layer.cout,
+                       "extra_reads": (1 if x.relu else 0) + (1 if x.grad_written else 0), "flags": L.ACCUM if x.grad_written else 0}
+                self.conv_records.append(rec)
+                a = L.ConvKsArgs()
+                a.x, a.ldx, a.cin = sd.ptr, sd.ld, 4 * cp
+                a.wp, a.n_pad, a.k_pad = s2d_img.data_ptr(), s2d_n_pad, s2d_k_pad
+                a.bias, a.nbias = None, 0
+                a.y, a.ldy = gx.ptr, gx.ld
+                a.mask, a.ldmask = (x.ptr, x.ld) if x.relu else (None, 0)
+                a.n0, a.n = 0, round_up(layer.cin, 4)
+                a.B, a.H, a.W = x.B, x.H, x.W
+                a.mode, a.flags, a.dtype = 6, (L.ACCUM if x.grad_written else 0), code
+
+                def convt3_dgrad(stream, a=a, keep=(sd.buf, gx.buf, s2d_img)):
+                    L.check(lib.dd_conv3x3_ks(C.byref(a), stream))
+                convt3_dgrad.tag, convt3_dgrad.info = "conv_igemm", rec
+                self.bwd(convt3_dgrad)
+                x.mark_grad_written()
+
         def backward():
             if not y.grad_written:
                 return
+            if s2d_bwd:
+                return backward_s2d()
             gy = y.grad()
             self._self_mask(y, gy)
             # out[t][co][ci] = sum_p gy[p (+) t][co] * z[p][ci] == dKernel in TF layout [kh,kw,C_out,C_in]

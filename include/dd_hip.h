@@ -377,6 +377,26 @@ int dd_zero_stuff(const void* x, int ldx, void* y, int ldy, int C, int B, int H,
 int dd_zero_unstuff(const void* dy, int lddy, void* dx, int lddx, const void* mask, int ldmask, int C, int B, int H, int W,
                     int accumulate, int dtype, dd_stream stream);
 
+/* ---- backward of the 3x3/s2 transposed conv WITHOUT the zero-stuffed form (bf16 / f16 storage).  TensorFlow differentiates
+ * tf.layers.conv2d_transpose (Tiramisu.py:60-65) into a stride-2 conv of the output gradient (the data gradient) and a filter gradient over the
+ * output grid (Training.py:701-702).  With dy rearranged by output parity,
+ *   s[b][i][j][(py*2 + px)*cp + co] = dy[b][2i + py][2j + px][co]        (dd_space_to_depth2; cp = cout rounded up to 16, the padding zero),
+ * both become dense work on the INPUT grid:
+ *   dx[i][j][ci]     = sum over the 9 taps (a, b) of  s[i + (a == 2)][j + (b == 2)][plane(a, b)*cp + co] * K[a][b][co][ci],  plane = (a & 1)*2 + (b & 1)
+ *                      = dd_conv3x3_ks mode 6 over s (a 2 x 2-tap conv with offsets 0 / +1: 16 cout MACs per input pixel and ci against the 36 of
+ *                      the 3x3 conv over the zero-stuffed 2H x 2W image, and no stuffed tensors);
+ *   dK[a][b][co][ci] += sum_p s[p + off(a, b)][plane(a, b)*cp + co] * x[p][ci]      (dd_convt3_wgrad: exactly the 9 cout cin products per pixel).
+ * TensorFlow kernel layout [3][3][cout][cin], fp32 atomics: zero dK first. */
+int dd_space_to_depth2(const void* y, int ldy, void* s, int lds, int C, int cp, int B, int H, int W, int dtype, dd_stream stream);
+typedef struct {
+  const void* s; int lds; int cout; int cp;   /* space-to-depth output gradient [B,H,W,lds], lds >= 4 cp, cp % 16 == 0 */
+  const void* x; int ldx; int cin;            /* the layer's input [B,H,W,ldx]; channels up to the next multiple of 8 readable and zero */
+  float* dk;                                  /* [3][3][cout][cin] fp32 */
+  int B, H, W;                                /* input grid */
+  int dtype;
+} dd_convt3_wgrad_args;
+int dd_convt3_wgrad(const dd_convt3_wgrad_args* a, dd_stream stream);
+
 /* ---- host-side helper (no device work): CRC-32C (Castagnoli) of `n` bytes, continuing from `crc` (0 to start).  The checksum of
  * the reference's on-disk formats: TFRecord framing (TFRecordsCreator.py:233-252) and TensorFlow checkpoint bundles written by the
  * Estimator (Training.py:944-1000 model_dir).  Returns the plain (unmasked) CRC through *out. */

@@ -377,19 +377,30 @@ def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 64, 24), (1, 17, 21, 200, 96), (2, 16, 16, 136, 64), (1, 9, 35, 40, 16), (1, 16, 16, 1216, 96),
                                             (1, 16, 16, 168, 16), (1, 8, 8, 160, 24), (2, 20, 12, 328, 32)])      # narrow outputs over several K-slices
-def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout):
+@pytest.mark.parametrize("form", ["s2d", "stuffed", "s2d+mask+accumulate"])
+def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout, form, monkeypatch):
     """tf.layers.conv2d_transpose(3x3, strides 2, SAME).  bf16 / f16: the forward runs as the four output-parity sub-convolutions of
-    csrc/dd_conv_ks.hip (9 real taps on the input grid), the backward on the zero-stuffed form; f32: both on the zero-stuffed form."""
+    csrc/dd_conv_ks.hip (9 real taps on the input grid); the backward on the space-to-depth output gradient (dd_space_to_depth2 +
+    dd_conv3x3_ks mode 6 + dd_convt3_wgrad) or, DD_CONVT3_S2D_BWD=0, on the zero-stuffed form; f32: everything on the zero-stuffed form."""
+    if dtype == "f32" and form != "stuffed":
+        pytest.skip("f32 storage differentiates the zero-stuffed form only")
+    monkeypatch.setenv("DD_CONVT3_S2D_BWD", "0" if form == "stuffed" else "1")
+    masked = form.endswith("accumulate")
     gen = _gen(33)
     g = eng.Graph("cuda", dtype)
-    x = g.tensor(B, H, W, cin, requires_grad=True)
+    x = g.tensor(B, H, W, cin, requires_grad=True, relu=masked)
     lay = g.layer("t/conv2d_transpose", 3, cin, cout, "convT3")
     y = g.conv_transpose3(x, lay, relu=True)
     y.mark_grad_written()
+    if masked:
+        x.mark_grad_written()      # another consumer already stored its part of dx: this layer masks by x > 0 and adds
     g.build_backward()
     g.finalize()
     assert ("ks_convt" in [getattr(op, "__name__", "") for op in g.fwd_ops]) == (dtype != "f32")
+    assert ("convt3_wgrad" in [getattr(op, "__name__", "") for op in g.bwd_ops]) == (form != "stuffed")
     xv = representable(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64), dtype)
+    if masked:
+        xv = torch.relu(xv)
     wv = representable(torch.randn(3, 3, cout, cin, generator=gen, dtype=torch.float64) / (3 * cin ** 0.5), dtype)
     bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
     set_param(g.params, lay.kernel, wv); set_param(g.params, lay.bias, bv)
@@ -403,9 +414,14 @@ def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout):
     fill(y.grad(), gpre)
     grads = torch.autograd.grad((pre * gpre).sum(), [xo, wo, bo])
     g.params.grads.zero_()
+    want_dx = grads[0]
+    if masked:
+        g0 = representable(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64), dtype)
+        fill(x.grad(), g0)
+        want_dx = g0 + grads[0] * (xv > 0)
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
-    check("dx", read(x.grad()), grads[0], ROUND[dtype])
+    check("dx", read(x.grad()), want_dx, ROUND[dtype])
     check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], ACC32[dtype])
     check("db", g.params.grad(lay.bias).double().cpu(), grads[2], ACC32[dtype])
 
