@@ -295,6 +295,9 @@ static int ks_cus() {
 
 }  // namespace
 
+bool dd_conv_pw_taps_eligible(const dd_conv_ks_args* a);
+int dd_conv_pw_taps_launch(const dd_conv_ks_args* a, hipStream_t stream);
+
 extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->x && a->wp && a->y, "dd_conv3x3_ks: null pointer");
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_ks: storage dtype must be DD_BF16 or DD_F16");
@@ -310,6 +313,8 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
              "dd_conv3x3_ks: ldx=%d (%%8) ldy=%d (%%4) k_pad=%d (%%32) n_pad=%d (%%16) n0=%d (%%16) n=%d (%%4)", a->ldx, a->ldy, a->k_pad, a->n_pad, a->n0, a->n);
   DD_REQUIRE(a->n0 + a->n <= a->n_pad && a->cin <= a->k_pad, "dd_conv3x3_ks: channel ranges exceed the packed weight image");
   DD_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)a->y % 8) == 0, "dd_conv3x3_ks: x / wp must be 16-byte, y 8-byte aligned");
+  // mode 6 with many output channels: 256-wide GEMM tiles over the linear pixel index (csrc/dd_conv_pw.hip)
+  if (dd_conv_pw_taps_eligible(a)) return dd_conv_pw_taps_launch(a, reinterpret_cast<hipStream_t>(stream));
   KsMulti m;
   KsP& p = m.p;
   p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;

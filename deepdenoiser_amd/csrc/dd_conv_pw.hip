@@ -21,6 +21,11 @@ struct PwP {
   long M;                       // pixels (B * H * W)
   int mtiles, nblk, nb_rows;    // pixel tiles of 256, channel blocks, channels per block (2 * CTN * 16)
   int relu, accum;
+  // ntaps == 4: the 2 x 2-tap conv over a space-to-depth tensor (data gradient of the 3x3 / s2 transposed conv, dd_conv3x3_ks mode 6): K-slice
+  // sl = (tap t, 64-channel chunk), tap t reads pixel (i + (t >> 1), j + (t & 1)) of the H x W grid (zero outside) against image tap
+  // (1 + (t >> 1)) * 3 + 1 + (t & 1) of a [9][n_pad][k_pad] weight image.  ntaps == 1: the plain 1x1 layer.
+  int ntaps, spt, H, W;         // taps, K-slices per tap, grid
+  long tap_stride;              // elements between image taps
 };
 
 typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
@@ -79,17 +84,27 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
   auto dma = [&](int it, int sl, unsigned buf) {
     const int pt = (it / a.nblk) * xcd_n + xcd, nb = it - (it / a.nblk) * a.nblk;
     const int rr = pw_opaque(r);
-    const int k = sl * 64 + ls * 8;
+    const int tap = a.ntaps > 1 ? sl / a.spt : 0;
+    const int k = (sl - tap * a.spt) * 64 + ls * 8;
+    const int tdy = tap >> 1, tdx = tap & 1;
+    const char* Wt = Wp + (a.ntaps > 1 ? ((1 + tdy) * 3 + 1 + tdx) * a.tap_stride * 2 : 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int id = c * 8 + wave;
       const long pix = (long)pt * PW_BM + id * 8 + rr;
 #ifdef PW_EXP_NO_X
-      const bool ok = false;
+      bool ok = false;
 #else
-      const bool ok = pix < a.M && k < a.cinv;
+      bool ok = pix < a.M && k < a.cinv;
 #endif
-      pw_dma_1k(ok ? X + (pix * a.ldx + k) * 2 : zero, buf + id * 1024);
+      long src = pix;
+      if (a.ntaps > 1) {      // (M < 2^31: checked by the host)
+        const unsigned up = (unsigned)pix, row = up / (unsigned)a.W;
+        const int gj = (int)(up - row * (unsigned)a.W), gi = (int)(row % (unsigned)a.H);
+        ok = ok && gi + tdy < a.H && gj + tdx < a.W;
+        src = pix + tdy * a.W + tdx;
+      }
+      pw_dma_1k(ok ? X + (src * a.ldx + k) * 2 : zero, buf + id * 1024);
     }
 #pragma unroll
     for (int c = 0; c < (WCH + 7) / 8; ++c) {
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
 #else
         const bool ok = row < a.n_pad && k < a.k_pad;
 #endif
-        pw_dma_1k(ok ? Wp + ((long)row * a.k_pad + k) * 2 : zero, buf + PW_XBYTES + id * 1024);
+        pw_dma_1k(ok ? Wt + ((long)row * a.k_pad + k) * 2 : zero, buf + PW_XBYTES + id * 1024);
       }
     }
   };
@@ -539,17 +554,10 @@ bool dd_conv_pw_eligible(const dd_conv_args* a) {
 static long g_pw_launches = 0;
 extern "C" long dd_conv_pw_count(void) { return g_pw_launches; }
 
-int dd_conv_pw_launch(const dd_conv_args* a, hipStream_t s) {
-  ++g_pw_launches;
-  PwP p;
-  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;
-  p.ldx = a->ldx; p.ldy = a->ldy; p.ldmask = a->ldmask; p.cinv = a->cin; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
-  p.nbias = a->bias ? a->nbias : 0; p.nslices = (a->cin + 63) / 64;
-  p.M = (long)a->B * a->H * a->W;
+static int pw_plan_and_launch(PwP& p, int dtype, bool in_relu, hipStream_t s) {
   p.mtiles = (int)((p.M + PW_BM - 1) / PW_BM);
-  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
   // channel blocks of at most 256; all blocks equally wide (two waves x CTN tiles of 16), CTN >= 3
-  const int nt = (a->n + 15) / 16;
+  const int nt = (p.n + 15) / 16;
   p.nblk = (nt + 15) / 16;
   int ctn = ((nt + p.nblk - 1) / p.nblk + 1) / 2;
   if (ctn < 3) ctn = 3;
@@ -559,10 +567,41 @@ int dd_conv_pw_launch(const dd_conv_args* a, hipStream_t s) {
   grid = grid / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > (items + 7) / 8 * 8) grid = (items + 7) / 8 * 8;
-  if (a->dtype == DD_BF16) pw_launch<bf16_t>(p, ctn, (a->flags & DD_IN_RELU) != 0, (unsigned)grid, s);
-  else pw_launch<f16_t>(p, ctn, (a->flags & DD_IN_RELU) != 0, (unsigned)grid, s);
+  if (dtype == DD_BF16) pw_launch<bf16_t>(p, ctn, in_relu, (unsigned)grid, s);
+  else pw_launch<f16_t>(p, ctn, in_relu, (unsigned)grid, s);
   DD_LAUNCH_CHECK();
   return DD_OK;
+}
+
+int dd_conv_pw_launch(const dd_conv_args* a, hipStream_t s) {
+  ++g_pw_launches;
+  PwP p;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldmask = a->ldmask; p.cinv = a->cin; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
+  p.nbias = a->bias ? a->nbias : 0; p.nslices = (a->cin + 63) / 64;
+  p.M = (long)a->B * a->H * a->W;
+  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
+  p.ntaps = 1; p.spt = p.nslices; p.H = a->H; p.W = a->W; p.tap_stride = 0;
+  return pw_plan_and_launch(p, a->dtype, (a->flags & DD_IN_RELU) != 0, s);
+}
+
+// dd_conv3x3_ks mode 6 with many output channels: the K-streamed kernel covers 64 of them per pass over the (small) input; here 256.
+bool dd_conv_pw_taps_eligible(const dd_conv_ks_args* a) {
+  if (!pw_enabled() || a->mode != 6 || a->n <= 128 || a->n0 != 0) return false;
+  if ((long)a->B * a->H * a->W >= (1L << 31) || (long)a->B * a->H * a->W < 2048) return false;
+  return a->cin % 8 == 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0 && ((uintptr_t)a->y % 16) == 0 && (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
+}
+
+int dd_conv_pw_taps_launch(const dd_conv_ks_args* a, hipStream_t s) {
+  ++g_pw_launches;
+  PwP p;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.mask = a->mask; p.y = a->y;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldmask = a->ldmask; p.cinv = a->cin; p.n = a->n; p.n_pad = a->n_pad; p.k_pad = a->k_pad;
+  p.nbias = a->bias ? a->nbias : 0;
+  p.M = (long)a->B * a->H * a->W;
+  p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
+  p.ntaps = 4; p.spt = (a->cin + 63) / 64; p.nslices = 4 * p.spt; p.H = a->H; p.W = a->W; p.tap_stride = (long)a->n_pad * a->k_pad;
+  return pw_plan_and_launch(p, a->dtype, false, s);
 }
 
 // 1x1 weight gradients with more than 64 channels on either side (conv2d form: bias gradient from Q or none), bf16 / f16 storage.

@@ -376,7 +376,8 @@ def test_conv_transpose_2x2(eng, dtype, cin, cout, H, W):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 64, 24), (1, 17, 21, 200, 96), (2, 16, 16, 136, 64), (1, 9, 35, 40, 16), (1, 16, 16, 1216, 96),
-                                            (1, 16, 16, 168, 16), (1, 8, 8, 160, 24), (2, 20, 12, 328, 32)])      # narrow outputs over several K-slices
+                                            (1, 16, 16, 168, 16), (1, 8, 8, 160, 24), (2, 20, 12, 328, 32),      # narrow outputs over several K-slices
+                                            (2, 32, 40, 328, 32), (1, 48, 45, 1216, 96)])      # >= 2048 pixels, > 128 input channels: data gradient as GEMM tiles
 @pytest.mark.parametrize("form", ["s2d", "stuffed", "s2d+mask+accumulate"])
 def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout, form, monkeypatch):
     """tf.layers.conv2d_transpose(3x3, strides 2, SAME).  bf16 / f16: the forward runs as the four output-parity sub-convolutions of
@@ -398,6 +399,7 @@ def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout, form, monkeypatch):
     g.finalize()
     assert ("ks_convt" in [getattr(op, "__name__", "") for op in g.fwd_ops]) == (dtype != "f32")
     assert ("convt3_wgrad" in [getattr(op, "__name__", "") for op in g.bwd_ops]) == (form != "stuffed")
+    pw_before = eng.L.load().dd_conv_pw_count()
     xv = representable(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64), dtype)
     if masked:
         xv = torch.relu(xv)
@@ -424,6 +426,8 @@ def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout, form, monkeypatch):
     check("dx", read(x.grad()), want_dx, ROUND[dtype])
     check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], ACC32[dtype])
     check("db", g.params.grad(lay.bias).double().cpu(), grads[2], ACC32[dtype])
+    if form != "stuffed":      # the data gradient of wide inputs on large grids runs as 256-wide GEMM tiles (conv_pw_kernel with four taps)
+        assert eng.L.load().dd_conv_pw_count() - pw_before == (1 if (cin > 128 and B * H * W >= 2048) else 0)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
