@@ -1,4 +1,4 @@
-"""f32 storage path: cfg-2 training step (B = 32) and the heavy Tiramisu at 64x64, ms per step:  [DD_CONV_MAX_NT=4] python tools/f32_bench.py"""
+"""cfg-2 training step (B = 32) and the heavy Tiramisu (B = 8, 256x256), ms per step, eager launches:  python tools/f32_bench.py [f32|bf16|f16]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -16,5 +16,5 @@ for name, aj, B, T in (("cfg-2 B=32", configs.cfg2_unet_kpcn(), 32, 128), ("cfg-
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): tr.step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-    print("MAX_NT=%s %s %s: %.2f ms/step %.1f tiles/s" % (os.environ.get("DD_CONV_MAX_NT", "8"), name, DT, dt * 1e3, B / dt))
+    print("%s %s: %.2f ms/step %.1f tiles/s" % (name, DT, dt * 1e3, B / dt))
     del tr, arch; torch.cuda.empty_cache()
