@@ -202,6 +202,21 @@ class ConvLayer:
         return self._packed[role]
 
 
+def convt3_s2d_blocks():
+    """The nine (a, b) taps of the 3x3 / stride-2 transposed conv as seen from the INPUT grid once the output gradient is rearranged by output
+    parity, s[i][j][plane*cp + co] = dy[2i + py][2j + px][co] with plane = py*2 + px (dd_space_to_depth2):
+        dx[i][j][ci]      = sum_(a,b) sum_co s[i + di][j + dj][plane*cp + co] * K[a][b][co][ci]
+        dK[a][b][co][ci]  = sum_(i,j)        s[i + di][j + dj][plane*cp + co] * x[i][j][ci]
+    Returns [(a, b, di, dj, plane, image_tap)]: output row o = 2i + a is row i of parity a & 1 for a < 2 and row i + 1 of parity
+    0 for a = 2; image_tap = (1 + di)*3 + (1 + dj) is where dd_conv3x3_ks mode 6 (taps at offsets 0 / +1) expects the block."""
+    out = []
+    for a in range(3):
+        for b in range(3):
+            di, dj = int(a == 2), int(b == 2)
+            out.append((a, b, di, dj, (a & 1) * 2 + (b & 1), (1 + di) * 3 + (1 + dj)))
+    return out
+
+
 class Graph:
     def __init__(self, device, dtype="f32", params=None):
         assert dtype in _CODE
@@ -651,13 +666,10 @@ class Graph:
             cp = round_up(layer.cout, 16)
             s2d_n_pad, s2d_k_pad = round_up(layer.cin, 16), round_up(4 * cp, 64 // _ESZ[self.dtype])
             s2d_img = torch.zeros(9 * s2d_n_pad * s2d_k_pad, dtype=_TORCH_DT[self.dtype], device=self.device)
-            for ta in range(3):
-                for tb in range(3):
-                    tap_img = (1 + (ta == 2)) * 3 + (1 + (tb == 2))
-                    plane = (ta & 1) * 2 + (tb & 1)
-                    self.register_pack(layer.kernel, s2d_img, 1, layer.cin, layer.cout, s2d_n_pad, cp, 0, 1, layer.cin, 0,
-                                       src_offset=(ta * 3 + tb) * layer.cout * layer.cin,
-                                       dst_offset=tap_img * s2d_n_pad * s2d_k_pad + plane * cp, dst_ld=s2d_k_pad, dst_tap_stride=s2d_n_pad * s2d_k_pad)
+            for ta, tb, _, _, plane, tap_img in convt3_s2d_blocks():
+                self.register_pack(layer.kernel, s2d_img, 1, layer.cin, layer.cout, s2d_n_pad, cp, 0, 1, layer.cin, 0,
+                                   src_offset=(ta * 3 + tb) * layer.cout * layer.cin,
+                                   dst_offset=tap_img * s2d_n_pad * s2d_k_pad + plane * cp, dst_ld=s2d_k_pad, dst_tap_stride=s2d_n_pad * s2d_k_pad)
         if need_z:
             def stuff(stream):
                 L.check(lib.dd_zero_stuff(x.ptr, x.ld, z.ptr, z.ld, x.Cp, x.B, x.H, x.W, code, stream))
