@@ -46,7 +46,7 @@ struct WgradP {
   int ldp, m, ldq, n, mv, nv;   // mv/nv: staged (16-byte rounded) channel counts
   int B, H, W, taps, flags, bias_mode;
   int tiles_x, tiles_y, ksplit, mslices, nslices;
-  int ncombo, cstart[33];       // LDS-DMA kernel: workgroups [cstart[c], cstart[c+1]) split the pixel tiles of (ms, ns) = (c / nslices, c % nslices)
+  int ncombo, cstart[65];       // LDS-DMA kernel: workgroups [cstart[c], cstart[c+1]) split the pixel tiles of (ms, ns) = (c / nslices, c % nslices)
   int hin, win;
 };
 
@@ -677,8 +677,8 @@ static int launch_dma(WgradP& p, hipStream_t stream) {
   const int nc = p.mslices * p.nslices;
   const long total_tiles = (long)p.B * p.tiles_x * p.tiles_y;
   const int target = p.ksplit * nc;
-  if (nc > 32) { dd_set_error("dd_conv_wgrad: more than 32 channel-slice pairs"); return DD_ERR_INVALID; }
-  int w[32], wsum = 0;
+  if (nc > 64) { dd_set_error("dd_conv_wgrad: more than 64 channel-slice pairs"); return DD_ERR_INVALID; }
+  int w[64], wsum = 0;
   for (int c = 0; c < nc; ++c) {
     const int ns = c % p.nslices;
     const int nvalid = p.n - ns * 64 < 64 ? p.n - ns * 64 : 64;
@@ -726,9 +726,9 @@ static bool dma_enabled() {
 
 template <typename T>
 int dispatch(const WgradP& p, hipStream_t stream) {
-  // (more than 32 channel-slice pairs -- > ~360 x 360 channels, Tiramisu transitions with wide filters -- do not fit the kernel's split table:
-  //  those launches take the register-staged kernel below)
-  if (sizeof(T) == 2 && (p.taps == 9 || p.taps == 1) && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && p.mslices * p.nslices <= 32 && dma_enabled()) {
+  // (more than 64 channel-slice pairs -- > ~512 x 512 channels -- do not fit the kernel's split table: those launches take the register-staged
+  //  kernel below; round 3 raised the table from 32: the 1 088 -> 96 dense-block layer of the heavy Tiramisu is 17 x 2 pairs)
+  if (sizeof(T) == 2 && (p.taps == 9 || p.taps == 1) && p.bias_mode != 2 && !(p.flags & DD_GATHER2X2) && p.mslices * p.nslices <= 64 && dma_enabled()) {
     if constexpr (sizeof(T) == 2) {
       WgradP q = p;
       return launch_dma<T>(q, stream);
