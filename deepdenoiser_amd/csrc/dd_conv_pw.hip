@@ -86,8 +86,11 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
     const int rr = pw_opaque(r);
     const int tap = a.ntaps > 1 ? sl / a.spt : 0;
     const int k = (sl - tap * a.spt) * 64 + ls * 8;
-    const int tdy = tap >> 1, tdx = tap & 1;
-    const char* Wt = Wp + (a.ntaps > 1 ? ((1 + tdy) * 3 + 1 + tdx) * a.tap_stride * 2 : 0);
+    // 4 taps: offsets 0 / +1, image taps (1..2, 1..2);  9 taps: offsets -1 .. +1, image tap = tap
+    const int t3 = (tap * 11) >> 5;      // tap / 3 for tap < 9
+    const int tdy = a.ntaps == 9 ? t3 - 1 : tap >> 1, tdx = a.ntaps == 9 ? tap - 3 * t3 - 1 : tap & 1;
+    const int img = a.ntaps == 9 ? tap : a.ntaps == 4 ? (1 + tdy) * 3 + 1 + tdx : 0;
+    const char* Wt = Wp + img * a.tap_stride * 2;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int id = c * 8 + wave;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
       if (a.ntaps > 1) {      // (M < 2^31: checked by the host)
         const unsigned up = (unsigned)pix, row = up / (unsigned)a.W;
         const int gj = (int)(up - row * (unsigned)a.W), gi = (int)(row % (unsigned)a.H);
-        ok = ok && gi + tdy < a.H && gj + tdx < a.W;
+        ok = ok && (unsigned)(gi + tdy) < (unsigned)a.H && (unsigned)(gj + tdx) < (unsigned)a.W;
         src = pix + tdy * a.W + tdx;
       }
       pw_dma_1k(ok ? X + (src * a.ldx + k) * 2 : zero, buf + id * 1024);
@@ -278,6 +281,11 @@ bool pw_enabled() {
 int pw_min_k() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DD_CONV_PW_MIN_K"); v = e ? atoi(e) : 0; }
+  return v;
+}
+int pw_gather9() {      // DD_CONV_PW_GATHER=0: wide gather-form data gradients stay on the K-streamed kernel
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DD_CONV_PW_GATHER"); v = e ? atoi(e) : 1; }
   return v;
 }
 int pwg_mid() {      // DD_WGRAD_PW_MID=1: also take the mid-sized gradients (129 ... 256 channels on the wider side)
@@ -587,7 +595,10 @@ int dd_conv_pw_launch(const dd_conv_args* a, hipStream_t s) {
 
 // dd_conv3x3_ks mode 6 with many output channels: the K-streamed kernel covers 64 of them per pass over the (small) input; here 256.
 bool dd_conv_pw_taps_eligible(const dd_conv_ks_args* a) {
-  if (!pw_enabled() || a->mode != 6 || a->n <= 128 || a->n0 != 0) return false;
+  // mode 6 (any epilogue it takes), or mode 0 with the gradient epilogue (the gather-form data gradient of a wide dense-block prefix)
+  const bool grad_epi = (a->flags & DD_ACCUM) != 0 || a->mask != nullptr;
+  if (!pw_enabled() || !(a->mode == 6 || (a->mode == 0 && grad_epi && pw_gather9())) || a->n <= 128 || a->n0 != 0) return false;
+  if (a->flags & (DD_IN_RELU | DD_OUT_RELU)) return false;
   if ((long)a->B * a->H * a->W >= (1L << 31) || (long)a->B * a->H * a->W < 2048) return false;
   return a->cin % 8 == 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0 && ((uintptr_t)a->y % 16) == 0 && (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
 }
@@ -600,7 +611,7 @@ int dd_conv_pw_taps_launch(const dd_conv_ks_args* a, hipStream_t s) {
   p.nbias = a->bias ? a->nbias : 0;
   p.M = (long)a->B * a->H * a->W;
   p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
-  p.ntaps = 4; p.spt = (a->cin + 63) / 64; p.nslices = 4 * p.spt; p.H = a->H; p.W = a->W; p.tap_stride = (long)a->n_pad * a->k_pad;
+  p.ntaps = a->mode == 6 ? 4 : 9; p.spt = (a->cin + 63) / 64; p.nslices = p.ntaps * p.spt; p.H = a->H; p.W = a->W; p.tap_stride = (long)a->n_pad * a->k_pad;
   return pw_plan_and_launch(p, a->dtype, false, s);
 }
 

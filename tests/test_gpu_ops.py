@@ -101,7 +101,8 @@ def test_conv_k_streamed_dense_block_layers(eng, dtype, cin, cout, H, W, B):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("form", ["gather", "scatter"])
-@pytest.mark.parametrize("c0,f,n,H,W,B", [(16, 16, 3, 20, 28, 2), (40, 24, 4, 16, 16, 1), (64, 32, 2, 17, 33, 2), (96, 64, 3, 16, 16, 1)])
+@pytest.mark.parametrize("c0,f,n,H,W,B", [(16, 16, 3, 20, 28, 2), (40, 24, 4, 16, 16, 1), (64, 32, 2, 17, 33, 2), (96, 64, 3, 16, 16, 1),
+                                          (160, 32, 2, 48, 45, 1)])      # a prefix wider than 128 channels on >= 2048 pixels: its gather runs as GEMM tiles
 def test_dense_block_backward_gather_and_scatter_forms(eng, dtype, form, c0, f, n, H, W, B, monkeypatch):
     """engine.Graph.dense_block (Tiramisu.py:26-41): n pre-activation 3x3 convs appending f channels each to a concat buffer, differentiated in
     gather form (one K-streamed launch per channel range: all later convs' contributions at once, rounded once; csrc/dd_conv_ks.hip DD_ACCUM with
@@ -148,8 +149,11 @@ def test_dense_block_backward_gather_and_scatter_forms(eng, dtype, form, c0, f, 
     buf.grad().buf[..., :total] = G.to(buf.buf.dtype).cuda()
     g.params.grads.zero_()
     grads = torch.autograd.grad((full * G).sum(), [xo] + ws + bs)
+    pw_before = eng.L.load().dd_conv_pw_count()
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
+    if form == "gather" and dtype != "f32":      # conv_pw_kernel with nine taps takes the prefix gather of the wide case, conv_ks_kernel the rest
+        assert eng.L.load().dd_conv_pw_count() - pw_before == (1 if (c0 > 128 and B * H * W >= 2048) else 0)
     # Measured (profiles/r03_parity_errors.txt).  Gather form: every range is rounded ONCE, exactly where the oracle chain rounds it -- the prefix
     # gradient agrees to 2e-7 ... 6e-5 and dW to 6e-8 ... 6e-5 (the upper end: one stored value on the other side of a rounding boundary).
     # Scatter form: the running sum is rounded once per contributing conv -- prefix 3.5e-3 (bf16) / 4.4e-4 (fp16), dW up to 3.1e-3 / 3.7e-4.
