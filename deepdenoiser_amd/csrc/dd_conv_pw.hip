@@ -26,6 +26,9 @@ struct PwP {
   // (1 + (t >> 1)) * 3 + 1 + (t & 1) of a [9][n_pad][k_pad] weight image.  ntaps == 1: the plain 1x1 layer.
   int ntaps, spt, H, W;         // taps, K-slices per tap, grid
   long tap_stride;              // elements between image taps
+  // ntaps == 4: the K-slices that hold data.  The operand of mode 6 is block-sparse -- tap (dy, dx) only meets the parity planes with py <= 1 - dy,
+  // px <= 1 - dx (9 of 16 (tap, plane) blocks) -- so the host lists the (tap, 64-channel chunk) pairs that intersect a non-zero block
+  unsigned char sl_tap[40], sl_chunk[40];
 };
 
 typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
   auto dma = [&](int it, int sl, unsigned buf) {
     const int pt = (it / a.nblk) * xcd_n + xcd, nb = it - (it / a.nblk) * a.nblk;
     const int rr = pw_opaque(r);
-    const int tap = a.ntaps > 1 ? sl / a.spt : 0;
-    const int k = (sl - tap * a.spt) * 64 + ls * 8;
+    const int tap = a.ntaps == 4 ? a.sl_tap[sl] : a.ntaps > 1 ? sl / a.spt : 0;
+    const int k = (a.ntaps == 4 ? a.sl_chunk[sl] : sl - tap * a.spt) * 64 + ls * 8;
     // 4 taps: offsets 0 / +1, image taps (1..2, 1..2);  9 taps: offsets -1 .. +1, image tap = tap
     const int t3 = (tap * 11) >> 5;      // tap / 3 for tap < 9
     const int tdy = a.ntaps == 9 ? t3 - 1 : tap >> 1, tdx = a.ntaps == 9 ? tap - 3 * t3 - 1 : tap & 1;
@@ -600,6 +603,7 @@ bool dd_conv_pw_taps_eligible(const dd_conv_ks_args* a) {
   if (!pw_enabled() || !(a->mode == 6 || (a->mode == 0 && grad_epi && pw_gather9())) || a->n <= 128 || a->n0 != 0) return false;
   if (a->flags & (DD_IN_RELU | DD_OUT_RELU)) return false;
   if ((long)a->B * a->H * a->W >= (1L << 31) || (long)a->B * a->H * a->W < 2048) return false;
+  if (a->mode == 6 && (a->cin % 4 != 0 || 4 * ((a->cin + 63) / 64) > 40)) return false;
   return a->cin % 8 == 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0 && ((uintptr_t)a->y % 16) == 0 && (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
 }
 
@@ -612,6 +616,20 @@ int dd_conv_pw_taps_launch(const dd_conv_ks_args* a, hipStream_t s) {
   p.M = (long)a->B * a->H * a->W;
   p.relu = (a->flags & DD_OUT_RELU) != 0; p.accum = (a->flags & DD_ACCUM) != 0;
   p.ntaps = a->mode == 6 ? 4 : 9; p.spt = (a->cin + 63) / 64; p.nslices = p.ntaps * p.spt; p.H = a->H; p.W = a->W; p.tap_stride = (long)a->n_pad * a->k_pad;
+  if (p.ntaps == 4) {      // cin = 4 cp channels, plane pl = channels [pl*cp, (pl+1)*cp); tap (dy, dx) meets plane (py, px) iff py <= 1 - dy and px <= 1 - dx
+    const int cp = a->cin / 4;
+    int ns = 0;
+    for (int t = 0; t < 4; ++t)
+      for (int c = 0; c < p.spt; ++c) {
+        bool live = false;
+        for (int pl = 0; pl < 4; ++pl) {
+          const bool meets = (pl >> 1) <= 1 - (t >> 1) && (pl & 1) <= 1 - (t & 1);
+          if (meets && pl * cp < (c + 1) * 64 && (pl + 1) * cp > c * 64) live = true;
+        }
+        if (live) { p.sl_tap[ns] = (unsigned char)t; p.sl_chunk[ns] = (unsigned char)c; ++ns; }
+      }
+    p.nslices = ns;
+  }
   return pw_plan_and_launch(p, a->dtype, false, s);
 }
 
