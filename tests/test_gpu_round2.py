@@ -12,6 +12,8 @@ The float64 oracle runs a 128x128 cfg-2 tile forward in well under a second on t
 """
 import copy
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -125,15 +127,28 @@ def test_cfg5_full_frame_1080p_matches_the_oracle_tile_by_tile():
     t, o, hc, wc, windows = tiling_ref.plan(H, W, T, O)
     assert (t, o, hc, wc) == (T, O, 11, 19)
     key = Naming.feature_prediction_name("Emission")
+    # The f64 oracle needs ~0.45 s per tile on the host.  By default it runs the tile rows that differ in kind -- the first (top crop), one
+    # interior row, the last two (the last row's origin is clamped to N - T, Prediction.py:283-296, so its crop overlaps its neighbour's) --
+    # and the frame is compared on the output rows those tiles own; DD_FULL_FRAME_ORACLE=1 runs all 11 rows (209 tiles, ~95 s).
+    full = os.environ.get("DD_FULL_FRAME_ORACLE", "0") != "0"
+    pick = list(range(hc)) if full else [0, 5, hc - 2, hc - 1]
     rows = []
     with torch.no_grad():
         for hi in range(hc):             # one row of 19 tiles per oracle call
+            if hi not in pick:
+                rows.append([np.zeros((T, T, 3)) for _ in range(wc)])
+                continue
             batch = {k: torch.stack([v[windows[hi][wi][0]:windows[hi][wi][1], windows[hi][wi][2]:windows[hi][wi][3]] for wi in range(wc)])
                      for k, v in frame.items()}
             out = oracle.predict(batch)[0][key]
             rows.append([out[wi].numpy() for wi in range(wc)])
     want = torch.from_numpy(np.asarray(tiling_ref.stitch(rows, H, W, T, O)))
     assert tuple(want.shape) == (H, W, 3)
+    # output rows owned by the picked tile rows: stitch a frame of row markers through the same plan
+    marks = [[np.full((T, T, 3), float(hi in pick)) for _ in range(wc)] for hi in range(hc)]
+    owned = torch.from_numpy(np.asarray(tiling_ref.stitch(marks, H, W, T, O)))[:, 0, 0] > 0.5
+    assert int(owned.sum()) >= (H if full else 3 * (T - 2 * O))
+    want = want[owned]
     errs = {}
     for dtype, tol in (("f32", 1e-4), ("f16", 1.3e-3), ("bf16", 1e-2)):      # measured 1.2e-6 / 8.1e-4 / 6.7e-3
         arch = Architecture(aj, device="cuda", dtype=dtype)
@@ -142,7 +157,8 @@ def test_cfg5_full_frame_1080p_matches_the_oracle_tile_by_tile():
         arch.params.load_list(list(oracle.vs.vars.values()))
         got = pred.predict_frame(frame)[key].cpu().double()
         torch.cuda.synchronize()
-        assert got.shape == want.shape and torch.isfinite(got).all()
+        assert tuple(got.shape) == (H, W, 3) and torch.isfinite(got).all()
+        got = got[owned]
         errs[dtype] = rel_l2(got, want)
         assert errs[dtype] < tol, (dtype, errs[dtype])
     print("cfg-5 1080p frame vs f64 oracle, rel-L2: " + ", ".join("%s %.3e" % kv for kv in errs.items()))
