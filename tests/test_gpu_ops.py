@@ -599,3 +599,69 @@ def test_conv_fused_backward_wide_layers_opt_in(eng, dtype, cin, cout, H, W, mon
     into dx (opt-in, DD_FUSE_CONV_BWD_WIDE=1: measured slower than the split path, kept correct)."""
     monkeypatch.setenv("DD_FUSE_CONV_BWD_WIDE", "1")
     _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, expect_fused_bwd=True)
+
+
+# The GEMM-tile kernels on channel VIEWS of concat buffers, which is how the Tiramisu lowering calls them (row pitch wider than the channel count,
+# non-zero channel offsets, neighbours that must not be touched): the 1x1 transition conv reads buf[:, c0:c0+C] and its data gradient is masked by
+# and accumulated into the same range of the gradient buffer; the transposed conv reads such a view and writes the next level's range.
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("kind,C,cout,c0,ld,H,W,B", [("1x1", 176, 176, 40, 256, 128, 128, 2), ("1x1", 80, 320, 8, 96, 181, 200, 1),
+                                                      ("convT3", 200, 32, 24, 232, 48, 45, 1), ("convT3", 136, 64, 64, 264, 32, 40, 2)])
+def test_gemm_tile_kernels_on_concat_views(lib, eng, dtype, kind, C, cout, c0, ld, H, W, B):
+    gen = _gen(C * 7 + cout)
+    g = eng.Graph("cuda", dtype)
+    wide = g.tensor(B, H, W, ld, relu=False)
+    wide.gstate["zero_init"] = True                       # a concat buffer: several writers, gradients accumulate
+    x = wide.view(c0, C, relu=False)
+    all_in = representable(torch.randn(B, H, W, ld, generator=gen, dtype=torch.float64), dtype)
+    if kind == "1x1":
+        lay = g.layer("v/conv2d", 1, C, cout)
+        y = g.conv(x, lay, relu=False, in_relu=True)
+        wshape = (1, 1, C, cout)
+    else:
+        out_buf = g.tensor(B, 2 * H, 2 * W, cout + 48, relu=False)
+        lay = g.layer("v/conv2d_transpose", 3, C, cout, "convT3")
+        y = g.conv_transpose3(x, lay, out=out_buf.view(16, cout, relu=False), relu=True)
+        wshape = (3, 3, cout, C)
+    y.mark_grad_written()
+    g.build_backward()
+    g.finalize()
+    wv = representable(torch.randn(wshape, generator=gen, dtype=torch.float64) / (C ** 0.5 * (1 if kind == "1x1" else 3)), dtype)
+    bv = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
+    set_param(g.params, lay.kernel, wv); set_param(g.params, lay.bias, bv)
+    wide.buf.copy_(all_in.to(wide.buf.dtype))
+    if kind != "1x1":
+        out_buf.buf.fill_(7.0)                             # the neighbours of the written range must survive
+    before, wbefore = lib.dd_conv_pw_count(), lib.dd_wgrad_pw_count()
+    g.run(g.pack_ops); g.run(g.fwd_ops)
+    xo = all_in[..., c0:c0 + C].clone().requires_grad_(True)
+    wo, bo = wv.clone().requires_grad_(True), bv.clone().requires_grad_(True)
+    if kind == "1x1":
+        pre = T.conv2d_same(torch.relu(xo), wo, bo, False)
+        yo = pre
+    else:
+        pre = T.conv2d_transpose_s2(xo, wo, bo, False)
+        yo = torch.relu(pre)
+    check("y", read(y), yo.detach(), ROUND[dtype])
+    if kind != "1x1":
+        assert float((out_buf.buf[..., :16].float() - 7.0).abs().max()) == 0.0 and float((out_buf.buf[..., 16 + cout:].float() - 7.0).abs().max()) == 0.0
+    G = torch.randn(pre.shape, generator=gen, dtype=torch.float64)
+    gpre = representable(G * (pre.detach() > 0) if kind != "1x1" else G, dtype)
+    fill(y.grad(), gpre)
+    g0 = representable(torch.randn(B, H, W, ld, generator=gen, dtype=torch.float64), dtype)      # what other consumers already stored
+    wide.grad().buf.copy_(g0.to(wide.buf.dtype))
+    grads = torch.autograd.grad((pre * gpre).sum(), [xo, wo, bo])
+    g.params.grads.zero_()
+    g.run(g.bwd_ops)
+    torch.cuda.synchronize()
+    got = wide.grad().buf.double().cpu()
+    want = g0.clone()
+    want[..., c0:c0 + C] += grads[0]                        # (1x1: autograd already applied the in_relu mask; convT3: no mask)
+    check("d view", got[..., c0:c0 + C], want[..., c0:c0 + C], ROUND[dtype])
+    untouched = float((got[..., :c0] - g0[..., :c0]).abs().max()) == 0.0 and float((got[..., c0 + C:] - g0[..., c0 + C:]).abs().max()) == 0.0
+    assert untouched, "the gradient of the neighbouring channel ranges was touched"
+    check("dW", g.params.grad(lay.kernel).double().cpu(), grads[1], ACC32[dtype])
+    check("db", g.params.grad(lay.bias).double().cpu(), grads[2], ACC32[dtype])
+    hi, lo = max(C, cout), min(C, cout)
+    pw_wgrad = kind == "1x1" and not (128 < hi <= 256 and lo > 32)      # the mid-sized weight gradient stays on the 64 x 64-slice kernel
+    assert lib.dd_conv_pw_count() - before >= 1 and lib.dd_wgrad_pw_count() - wbefore == int(pw_wgrad)
