@@ -203,6 +203,23 @@ def test_cfg3_full_size_training_step_parity_f32():
     _plain_training_parity("cfg-3 256x256", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 1, 256, 256, "f32", 1e-4, 2e-5, 5e-4, 4e-3)      # measured 2.6e-4 / 1.6e-3
 
 
+# Measured (bf16 / f16): forward 4.4e-2 / 5e-3, loss 2.0e-5 / 9.9e-6, gradient median 0.70 / 0.30, max 1.47 / 0.70 -- the same figures to four
+# digits with DD_CONV_PW=0 DD_CONVT3_S2D_BWD=0 and with every round-3 kernel off (DD_CONV_KS=0 DD_CONVT3_PARITY=0 DD_DENSE_GATHER=0 as well): as
+# for the heavy configuration below, this random 60-layer net turns half-precision logit rounding into large weight changes of the kernel-
+# prediction softmax, whichever kernels run it.  The loss is gated tightly; the gradient gates are sanity bounds.
+@pytest.mark.parametrize("dtype,gates", [("bf16", (7e-2, 1e-3, 1.0, 2.5)), ("f16", (1e-2, 1e-3, 0.5, 1.2))])
+def test_cfg3_full_size_half_precision_runs_the_gemm_tile_kernels(dtype, gates):
+    """BASELINE config 3 at its real size in the storage types the bench runs it in (256x256, B = 1: 65 536 pixels at the first level, where the
+    1x1 transition conv, the head's data gradients and the transposed conv's backward take the GEMM-tile kernels of csrc/dd_conv_pw.hip inside the
+    real network -- channel views of the concat buffers, accumulating gradients), against the plain f64 oracle at the storage type's own error."""
+    _need_gpu()
+    from deepdenoiser_amd import _lib
+    lib = _lib.load()
+    before, wbefore = lib.dd_conv_pw_count(), lib.dd_wgrad_pw_count()
+    _plain_training_parity("cfg-3 256x256", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 1, 256, 256, dtype, *gates)
+    assert lib.dd_conv_pw_count() - before >= 4 and lib.dd_wgrad_pw_count() - wbefore >= 2, "the GEMM-tile kernels did not run"
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_cfg3_heavy_filters_deep_reduction_parity(dtype):
     """The heavy Tiramisu, F = [64, 96, 128] x 4 (12.9 M parameters), on a 64x64 tile: implicit-GEMM reductions up to K = 9 x 1 088 = 9 792 and
