@@ -245,8 +245,41 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
   const int r = lane >> 3, ls = (lane & 7) ^ r;
   const char* zero = reinterpret_cast<const char*>(&dd_zero16_v);
   const char* X = reinterpret_cast<const char*>(a.x);
+  // HOIST (8 waves: 152 / 222 registers, room for 12 more): this lane's byte offset inside the haloed tile and its (row, column) there are the same
+  // for every tile -- computed once, a piece costs a bounds check and one 64-bit add on a per-tile SCALAR base.  Recomputed per piece (the
+  // 12-wave build at 166 of its 168 registers; csrc/dd_conv_bwd.hip explains the opaque copy) it is ~35 vector instructions, five of them
+  // quarter-rate 32-bit multiplies and two 64-bit multiply-adds: 31 + 13 of those per tile and wave, a VALU load of the order of the MFMAs'.
+  constexpr bool HOIST = NW == 8;
+  int p_off[NPIECE], p_yx[NPIECE];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) {
+      const int id = k * NW + wave;
+      const int sl = id >= G::CH ? 1 : 0, c = id - sl * G::CH;
+      const int pix = c * 8 + r;
+      const int py = (pix * 3641) >> 16, px = pix - py * PW;
+      const int ch = sl * 64 + ls * 8;
+      p_off[k] = ((py * a.W + px) * a.ldx + ch) * 2;
+      p_yx[k] = (id < G::NCHUNK && ch < a.cinv && pix < PW * G::PH) ? ((py << 8) | px) : (255 << 8);      // never in range
+    }
+  }
   auto piece = [&](int k, const RwTile& t, unsigned buf) {
     const int id = k * NW + wave;
+    if constexpr (HOIST) {
+      if (id < G::NCHUNK) {      // wave-uniform
+        const int gy = t.y0 - 1 + (p_yx[k] >> 8), gx = t.x0 - 1 + (p_yx[k] & 255);
+#ifdef RW_EXP_NO_DMA
+        const bool ok = false;
+#else
+        const bool ok = t.live && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+#endif
+        // tile origin (haloed pixel (0, 0)): a wave-uniform 64-bit offset; rows above / left of the image are never dereferenced
+        const long base = ((((long)t.b * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * a.ldx) * 2;
+        const int sl = id >= G::CH ? 1 : 0, c = id - sl * G::CH;
+        rw_dma_1k(ok ? X + base + p_off[k] : zero, buf + sl * G::SLICE + c * 1024);
+      }
+      return;
+    }
     if (id < G::NCHUNK) {      // wave-uniform
       int rr = r;
       asm volatile("" : "+v"(rr));      // (keeps the per-piece coordinates from being hoisted out of the tile loop: see csrc/dd_conv_bwd.hip)
