@@ -84,8 +84,45 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
   const char* X = reinterpret_cast<const char*>(a.x);
   const char* Wp = reinterpret_cast<const char*>(a.wp);
   constexpr int WCH = 4 * CTN;      // weight chunks per block (2 * CTN * 16 rows / 8)
+  // this lane's byte offsets inside a pixel tile / a weight block are the same for every unit: computed once; per unit a SCALAR base is added
+  // (recomputed per chunk they are two 64-bit multiply-adds each: 16 quarter-rate vector instructions per unit next to its 64 MFMAs)
+  constexpr int WPC = (WCH + 7) / 8;
+  int xo[4], wo[WPC], xrow[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { xrow[c] = (c * 8 + wave) * 8 + r; xo[c] = (xrow[c] * a.ldx + ls * 8) * 2; }
+#pragma unroll
+  for (int c = 0; c < WPC; ++c) wo[c] = (((c * 8 + wave) * 8 + r) * a.k_pad + ls * 8) * 2;
   auto dma = [&](int it, int sl, unsigned buf) {
     const int pt = (it / a.nblk) * xcd_n + xcd, nb = it - (it / a.nblk) * a.nblk;
+    if (a.ntaps == 1) {      // the plain 1x1 layer: no pixel decomposition
+      const int k0 = sl * 64;
+      const long pix0 = (long)pt * PW_BM;
+      const char* xb = X + (pix0 * a.ldx + k0) * 2;
+      const char* wb = Wp + ((long)nb * a.nb_rows * a.k_pad + k0) * 2;
+      const bool k_ok = k0 + ls * 8 < a.cinv, kw_ok = k0 + ls * 8 < a.k_pad;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#ifdef PW_EXP_NO_X
+        const bool ok = false;
+#else
+        const bool ok = k_ok && pix0 + xrow[c] < a.M;
+#endif
+        pw_dma_1k(ok ? xb + xo[c] : zero, buf + (c * 8 + wave) * 1024);
+      }
+#pragma unroll
+      for (int c = 0; c < WPC; ++c) {
+        const int id = c * 8 + wave;
+        if (id < WCH) {      // wave-uniform
+#ifdef PW_EXP_NO_W
+          const bool ok = false;
+#else
+          const bool ok = kw_ok && nb * a.nb_rows + id * 8 + r < a.n_pad;
+#endif
+          pw_dma_1k(ok ? wb + wo[c] : zero, buf + PW_XBYTES + id * 1024);
+        }
+      }
+      return;
+    }
     const int rr = pw_opaque(r);
     const int tap = a.ntaps == 4 ? a.sl_tap[sl] : a.ntaps > 1 ? sl / a.spt : 0;
     const int k = (a.ntaps == 4 ? a.sl_chunk[sl] : sl - tap * a.spt) * 64 + ls * 8;

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       const int py = (pix * 3641) >> 16, px = pix - py * PW;
       const int ch = sl * 64 + ls * 8;
       p_off[k] = ((py * a.W + px) * a.ldx + ch) * 2;
-      p_yx[k] = (id < G::NCHUNK && ch < a.cinv && pix < PW * G::PH) ? ((py << 8) | px) : (255 << 8);      // never in range
+      p_yx[k] = (id < G::NCHUNK && ch < a.cinv && pix < PW * G::PH) ? ((py << 8) | px) : (0x7fff << 8);      // row 32 767 of the tile: never inside an image (a sentinel of 255 is in range of a 256-row image)
     }
   }
   auto piece = [&](int k, const RwTile& t, unsigned buf) {

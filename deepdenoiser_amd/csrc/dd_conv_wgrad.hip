@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
       const int pix = (k * 8 + wave) * 8 + r;
       const int py = (pix * 3641) >> 16, px = pix - py * PW;      // pix / 18 for pix < 400
       p_off[k] = ((py * a.win + px) * a.ldp + pch) * 2;
-      p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (255 << 8);     // dummy pixels of the last chunk: always out of range
+      p_yx[k] = pix < PW * PW ? ((py << 8) | px) : (0x7fff << 8);     // dummy pixels of the last chunk: always out of range (255 was not, for H >= 256: they then read row 17 of the tile into LDS slots nothing uses)
     } else {
       const int c = wave * PPC + k, py = c >> 1, px = (c & 1) * 8 + r;
       p_off[k] = ((py * a.win + px) * a.ldp + pch) * 2;

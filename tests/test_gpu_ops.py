@@ -65,6 +65,8 @@ CONV_CASES = [
     (3, 3, 16, 24, 24, True, False, False, False),       # cfg-1 first layer
     (1, 320, 320, 8, 8, False, True, False, False),      # Tiramisu transition-down
     (1, 400, 400, 8, 8, False, True, False, False),      # 7 x 7 channel-slice pairs: the weight gradient leaves the LDS-DMA kernel's split table
+    (3, 32, 64, 256, 264, True, False, False, False),    # images of >= 256 rows and a half-filled 64-channel slice: the lanes of the missing channels
+                                                         # must stay out of range whatever the image height (a row sentinel of 255 did not: round 3)
 ]
 
 
