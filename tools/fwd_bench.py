@@ -33,7 +33,10 @@ def timeit(fn, iters=20):
 
 
 print(os.environ.get("DD_LIB", "default"))
-for name, cin, cout, H, W, B, in_relu in SHAPES:
+ONLY = int(os.environ.get("FWD_ONLY", "-1"))
+for idx, (name, cin, cout, H, W, B, in_relu) in enumerate(SHAPES):
+    if ONLY >= 0 and idx != ONLY:
+        continue
     g = Graph("cuda", "bf16")
     x = g.tensor(B, H, W, cin, relu=not in_relu, requires_grad=False)
     x.buf.normal_()
