@@ -368,7 +368,9 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
 #pragma unroll
       for (int j = 0; j < FR; ++j) {
         const int f = yy * FR + j, dx = j / KC, kc = j - KC * dx;
+#ifndef RW_EXP_NO_MMA
         if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
+#endif
         if (j == 0 && yy < RH) acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
         if (j == 2 && yy >= 3) write_row(yy - 3);
         {      // the DMA pieces of the next tile, spread evenly over the first RW8_DMA_SPAN / 8 of the NF steps (the rest of the tile hides their latency)
@@ -378,11 +380,13 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
           if (k0 < NPIECE && (k0 * SPAN) / NPIECE == f) piece(k0, nxt, nbuf);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef RW_EXP_NO_MMA      // (knock-out build: the kernel as a pure mover of its input tiles and output rows)
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int y = yy - dy;
           if (y >= 0 && y < RH) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], ring[f % RING], acc[y % 4]);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
