@@ -600,6 +600,40 @@ class Graph:
         self.bwd(run)
         dst_tensor.mark_grad_written()
 
+    def conv_pair(self, x, layer1, layer2, relu1=True, relu2=True, out=None):
+        """Two consecutive tf.layers.conv2d(3x3, SAME) [+ ReLU] of the 64-channel level as ONE launch (csrc/dd_conv_pair.hip): forward only -- the
+        tensor between them exists in LDS only, so there is nothing to differentiate through.  The caller checks pair_eligible()."""
+        assert self.pair_eligible(x, layer1, layer2) and not bool(getattr(self, "training", True))
+        y = out if out is not None else self.tensor(x.B, x.H, x.W, layer2.cout, relu=relu2)
+        y.relu = relu2
+        ps, lib = self.params, self.lib
+        w1, _, n_pad1, k_pad1 = layer1.packed("fwd")
+        w2, _, n_pad2, k_pad2 = layer2.packed("fwd")
+        for lay in (layer1, layer2):
+            rec = {"flops": 2.0 * x.B * x.H * x.W * 9 * lay.cin * lay.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "n": lay.cout, "k": lay.cin,
+                   "extra_reads": 0, "flags": L.OUT_RELU}
+            self.conv_records.append(rec)
+
+        def conv_pair(stream, cell=[]):
+            if not cell:
+                a = L.ConvPairArgs()
+                a.x, a.ldx, a.cin = x.ptr, x.ld, x.Cp
+                a.w1, a.n_pad1, a.k_pad1, a.bias1, a.cmid, a.flags1 = w1.data_ptr(), n_pad1, k_pad1, ps.value_ptr(layer1.bias), layer1.cout, (L.OUT_RELU if relu1 else 0)
+                a.w2, a.n_pad2, a.k_pad2, a.bias2, a.cout, a.flags2 = w2.data_ptr(), n_pad2, k_pad2, ps.value_ptr(layer2.bias), round_up(layer2.cout, 4), (L.OUT_RELU if relu2 else 0)
+                a.y, a.ldy = y.ptr, y.ld
+                a.B, a.H, a.W, a.dtype = x.B, x.H, x.W, self.code
+                cell.append(a)
+            L.check(lib.dd_conv3x3_pair(C.byref(cell[0]), stream))
+        conv_pair.tag, conv_pair.info = "conv_igemm", {"flops": 2.0 * x.B * x.H * x.W * 9 * (layer1.cin * layer1.cout + layer2.cin * layer2.cout), "B": x.B, "H": x.H,
+                                                       "W": x.W, "taps": 9, "n": layer2.cout, "k": layer1.cin + layer2.cin, "flags": L.OUT_RELU}
+        self.fwd(conv_pair)
+        return y
+
+    def pair_eligible(self, x, layer1, layer2):
+        return (self.dtype in ("bf16", "f16") and layer1.kind == "conv" and layer2.kind == "conv" and layer1.k == 3 and layer2.k == 3
+                and x.C == layer1.cin and x.Cp <= 64 and 48 < layer1.cout <= 64 and layer1.cout % 16 == 0 and layer2.cin == layer1.cout and layer2.cout <= 64
+                and layer2.cout % 4 == 0 and x.ld % 8 == 0 and x.ch0 % 8 == 0 and os.environ.get("DD_CONV_PAIR", "1") != "0")
+
     def conv_transpose2(self, x, layer, out=None, relu=True):
         """tf.layers.conv2d_transpose(2x2, strides 2) + ReLU (UNet.py:54-59)."""
         assert layer.kind == "convT2" and x.C == layer.cin and layer.cout % 8 == 0
