@@ -19,6 +19,7 @@
 // of 8 channels; a lane's k-group picks its own tap), instead of 9 chunks with 8 of every 32 lanes idle.
 // Zero padding is TensorFlow's: every conv pads ITS input, so each layer's frame is forced to zero outside the image.
 #include "dd_common.h"
+#include <stdlib.h>
 
 #ifdef DD_PROFILE_PHASES
 // cycle stamps of workgroup 0 (tools/compose_phases.py): slot i accumulates the cycles between stamp i-1 and stamp i of the chosen thread
@@ -894,6 +895,8 @@ int g_cus = 0;
 
 }  // namespace
 
+int dd_compose_stream_fwd_launch(const dd_compose_args* a, hipStream_t s);      // csrc/dd_compose_stream.hip
+
 extern "C" int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->small && a->fine && a->out && a->w_in && a->b_in && a->w_out && a->b_out, "dd_compose_net_fwd: null pointer");
   for (int l = 0; l < 4; ++l) DD_REQUIRE(a->w_res[l] && a->b_res[l], "dd_compose_net_fwd: null residual-block weights");
@@ -905,6 +908,11 @@ extern "C" int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream) {
                "dd_compose_net_fwd: saved activation %d needs ld >= 24, ld %% 8 == 0 and 16-byte alignment", i);
   DD_REQUIRE(!a->save_netin || (a->ld_netin >= 8 && a->ld_netin % 8 == 0 && ((uintptr_t)a->save_netin % 16) == 0), "dd_compose_net_fwd: bad save_netin");
   DD_REQUIRE(!a->save_wl || a->ld_wl >= 1, "dd_compose_net_fwd: bad save_wl");
+  {
+    // round 4: the row-streaming kernel (csrc/dd_compose_stream.hip) is the forward; DD_COMPOSE_STREAM=0 keeps the 16x16-tile kernel below
+    static const bool stream_fwd = !(getenv("DD_COMPOSE_STREAM") && getenv("DD_COMPOSE_STREAM")[0] == '0');
+    if (stream_fwd) return dd_compose_stream_fwd_launch(a, reinterpret_cast<hipStream_t>(stream));
+  }
   ComposeP p;
   p.small = a->small; p.fine = a->fine; p.out = a->out;
   p.w_in = a->w_in; p.b_in = a->b_in; p.w_out = a->w_out; p.b_out = a->b_out;

@@ -279,6 +279,10 @@ typedef struct {
   int N, H, W, dtype;
 } dd_compose_args;
 int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream);
+/* Geometry dd_compose_net_fwd's row-streaming kernel (csrc/dd_compose_stream.hip) uses for an [N, H, W] launch on `cus` compute units:
+ * out8 = {frame width, rows per step, 32-pixel tasks per row, column strips, strip output width, band height, bands per image,
+ * virtual rows per band}.  Host-only (no device work); for tests and tools. */
+int dd_compose_stream_plan(int N, int H, int W, int cus, int* out8);
 
 /* Backward of dd_compose_net_fwd in ONE launch (TF autodiff of the same lines behind Training.py:701-702): d_fine is written, d_small is
  * written or accumulated into, every weight / bias gradient is ADDED to its fp32 arena slot (TensorFlow variable layout) with one
