@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "inference", "augment"],
                     help="inference: full-frame 1920x1080 halo-tiled prediction (BASELINE config 5), reported as MPix/s -- a secondary line, "
                          "the driver's contract is the default train mode")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch records of the profiling pass (family, shape, flops, us) to this JSON file")
     ap.add_argument("--host-inputs", action="store_true",
                     help="PCIe-inclusive variant (NOT the headline value): every step first copies its batch from pinned host memory")
     args = ap.parse_args()
@@ -370,8 +371,13 @@ def main():
         hf = {k: v.cpu().pin_memory() for k, v in feats.items()}
         hl = {k: v.cpu().pin_memory() for k, v in labels.items()}
 
+        # double-buffered staging on a copy stream: the upload of step k + 1 runs beside step k (deepdenoiser_amd.program.HostInputStager)
+        stager = trainer.program.host_stager()
+        stager.stage(hf, hl)
+
         def one_step():
-            trainer.program.set_inputs(hf, hl, non_blocking=True)
+            stager.consume()
+            stager.stage(hf, hl)
             trainer.step()
     else:
         one_step = trainer.step
@@ -393,7 +399,12 @@ def main():
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream (outside the timed region)
     roof = None
     if rank == 0:
-        times = trainer.program.profile_ops()           # {kernel family: (launches, total_ms, flops)}
+        times, launches = trainer.program.profile_ops(detail=True)           # {kernel family: (launches, total_ms, flops)}, per-launch records
+        if args.dump_launches:
+            # every launch of the step in program order: family, shape record (B, H, W, taps, n = C_out, k = C_in, flops, flags), HIP-event us --
+            # what `roofline` is computed from, so that `frac` can be recomputed per layer without reading engine.py
+            with open(args.dump_launches, "w") as fh:
+                json.dump([{"family": tag, "us": round(us, 2), **({k: v for k, v in info.items()} if info else {})} for tag, info, us in launches], fh, indent=0)
         fam = "conv_igemm"
         n, ms, flops = times[fam]
         achieved = flops / (ms * 1e-3) / 1e12
@@ -423,6 +434,15 @@ def main():
                                      "frac": v[2] / (v[1] * 1e-3) / 1e12 / peak} for k, v in convs.items()}
         tot_ms, tot_fl = sum(v[1] for v in convs.values()), sum(v[2] for v in convs.values())
         roof["all_conv_launches"] = {"ms_per_step": round(tot_ms, 3), "tflops": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak}
+        # the whole step against the same peak: algorithmic flops of forward + backward (every conv family incl. the transposed convs, the
+        # compose net 41 808 flop per fine pixel and the kernel-prediction head 2 C K + 2 K K + 6 K per pixel, each x 3 for fwd + bwd) over
+        # the TIMED step (value above), not over the profiled launches
+        NT_ = trainer.program.NF * B
+        extra_fl = sum(3.0 * NT_ * (H >> sc) * (W >> sc) * 41808.0 for sc in range(2)) + \
+            sum(3.0 * NT_ * (H >> sc) * (W >> sc) * (2.0 * c * 25 + 2.0 * 25 * 25 + 150.0) for sc, c in enumerate((64, 96, 128)))
+        step_fl = sum(v[2] for v in times.values()) + extra_fl
+        roof["whole_step"] = {"algorithmic_gflop_per_step": step_fl / 1e9, "ms_per_step": 1e3 * dt / args.steps,
+                              "tflops": step_fl / (dt / args.steps) / 1e12, "frac": step_fl / (dt / args.steps) / 1e12 / peak}
     if rank == 0:
         out = {
             "metric": "train tiles/sec (128x128x32ch U-Net KPCN)", "value": world * B * args.steps / dt, "unit": "tiles/s",
@@ -441,6 +461,25 @@ def main():
         }
         if world == 1 and not args.no_extras:
             out["extras"] = extras(device, B, H, W)
+            if not args.host_inputs:
+                # the same step fed from pinned host memory every step (PCIe-inclusive; never `value`): double-buffered staging on a copy stream
+                hf = {k: v.cpu().pin_memory() for k, v in feats.items()}
+                hl = {k: v.cpu().pin_memory() for k, v in labels.items()}
+                stager = trainer.program.host_stager()
+                stager.stage(hf, hl)
+                for i in range(args.warmup + args.steps):
+                    if i == args.warmup:
+                        torch.cuda.synchronize()
+                        th = time.perf_counter()
+                    stager.consume()
+                    stager.stage(hf, hl)
+                    trainer.step()
+                torch.cuda.synchronize()
+                dth = time.perf_counter() - th
+                out["extras"]["host_inputs"] = {"value": B * args.steps / dth, "unit": "tiles/s", "ms_per_step": 1e3 * dth / args.steps,
+                                                "frac_of_resident": (B * args.steps / dth) / out["value"],
+                                                "bytes_per_step": sum(v.numel() * v.element_size() for v in list(hf.values()) + list(hl.values())),
+                                                "inputs": "pinned host fp32, copied every step on a copy stream (2 staging slots), then device-to-device into the program's buffers"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(aj, tj, H, W)
         print(json.dumps(out))

@@ -33,6 +33,11 @@ void dd_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// ------------------------------------------------------------------------------------------------ per-device launch state
+// (csrc/dd_pointwise.hip) One process may drive several devices: what the launchers cache is keyed by the CURRENT device.
+int dd_device_cus();                          // compute units of the current device
+void dd_allow_max_lds(const void* kernel, int bytes = 160 * 1024);    // hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel)
+
 // ------------------------------------------------------------------------------------------------ element helpers
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

@@ -891,8 +891,6 @@ __global__ __launch_bounds__(BWD_THREADS) void compose_bwd_kernel(const ComposeB
   }
 }
 
-int g_cus = 0;
-
 }  // namespace
 
 int dd_compose_stream_fwd_launch(const dd_compose_args* a, hipStream_t s);      // csrc/dd_compose_stream.hip
@@ -923,20 +921,14 @@ extern "C" int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream) {
   p.N = a->N; p.H = a->H; p.W = a->W;
   p.tiles_x = dd_ceil_div(a->W, 16); p.tiles_y = dd_ceil_div(a->H, 16);
   p.total_tiles = a->N * p.tiles_x * p.tiles_y;
-  if (g_cus == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_cus <= 0) g_cus = 256;
-  }
-  const int grid = p.total_tiles < g_cus ? p.total_tiles : g_cus;
+  const int cus = dd_device_cus();
+  const int grid = p.total_tiles < cus ? p.total_tiles : cus;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == DD_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(compose_fwd_kernel<bf16_t>));
     hipLaunchKernelGGL(compose_fwd_kernel<bf16_t>, dim3(grid), dim3(512), LDS_TOTAL, s, p);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_fwd_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(compose_fwd_kernel<f16_t>));
     hipLaunchKernelGGL(compose_fwd_kernel<f16_t>, dim3(grid), dim3(512), LDS_TOTAL, s, p);
   }
   DD_LAUNCH_CHECK();
@@ -964,20 +956,14 @@ extern "C" int dd_compose_net_bwd(const dd_compose_bwd_args* a, dd_stream stream
   p.N = a->N; p.H = a->H; p.W = a->W;
   p.tiles_x = dd_ceil_div(a->W, 16); p.tiles_y = dd_ceil_div(a->H, 16);
   p.total_tiles = a->N * p.tiles_x * p.tiles_y;
-  if (g_cus == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_cus <= 0) g_cus = 256;
-  }
-  const int grid = p.total_tiles < g_cus ? p.total_tiles : g_cus;
+  const int cus = dd_device_cus();
+  const int grid = p.total_tiles < cus ? p.total_tiles : cus;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == DD_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(compose_bwd_kernel<bf16_t>));
     hipLaunchKernelGGL(compose_bwd_kernel<bf16_t>, dim3(grid), dim3(BWD_THREADS), LDS_BWD, s, p);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_bwd_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(compose_bwd_kernel<f16_t>));
     hipLaunchKernelGGL(compose_bwd_kernel<f16_t>, dim3(grid), dim3(BWD_THREADS), LDS_BWD, s, p);
   }
   DD_LAUNCH_CHECK();

@@ -39,8 +39,7 @@
 // Bands of rows are concatenated into one stream of "virtual rows" (each band contributes its rows plus 4 halo rows either side; the rows a
 // stage produces across a band junction are garbage that no valid output depends on), so the pipeline fills and drains once per launch.
 // Images wider than 128 columns are cut into column strips with a 4-column halo (the only recompute left).
-#include "dd_common.h"
-#include <type_traits>
+#include "dd_compose_stream.h"
 
 #ifdef CS_PROFILE
 // cycle stamps of workgroup 0, task-slot-0 wave of every layer (tools/compose_stream_phases.py): [layer][phase] accumulated cycles
@@ -60,59 +59,6 @@ extern "C" int dd_debug_cs_phases(unsigned long long* out32, int reset) {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(2))) unsigned int cs_u32x2;
-
-template <typename T> __device__ __forceinline__ f32x16_t mma32(uint4 a, uint4 b, f32x16_t c);
-template <> __device__ __forceinline__ f32x16_t mma32<bf16_t>(uint4 a, uint4 b, f32x16_t c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x16_t mma32<f16_t>(uint4 a, uint4 b, f32x16_t c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-}
-
-// The first MFMA of a chain, from a ZERO accumulator given as the instruction's inline constant.  (Through the builtin hipcc keeps a vector of
-// 16 zero registers alive across the whole step loop as that operand -- or moves zeros into the accumulator every time.)  The chain that
-// follows reads the result as its C operand, which needs no wait states; the operands come straight from LDS reads, whose waits the compiler
-// inserts for inline asm as for any other use.
-typedef __attribute__((ext_vector_type(4))) unsigned int cs_u32x4;
-template <typename T> __device__ __forceinline__ f32x16_t mma32_zero(uint4 a, uint4 b);
-template <> __device__ __forceinline__ f32x16_t mma32_zero<bf16_t>(uint4 a, uint4 b) {
-  f32x16_t d;
-  const cs_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(av), "v"(bv));
-  return d;
-}
-template <> __device__ __forceinline__ f32x16_t mma32_zero<f16_t>(uint4 a, uint4 b) {
-  f32x16_t d;
-  const cs_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(av), "v"(bv));
-  return d;
-}
-
-template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
-template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
-template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float& lo, float& hi) { unpack_f16x2(w, lo, hi); }
-// One conversion instruction per pair.  (Followed directly by an integer operation on the halves -- the packed ReLU, a select -- hipcc converts
-// each value on its own and merges them with a v_perm_b32: three instructions per pair.  The empty asm hides the origin of the word.)
-template <typename T> __device__ __forceinline__ uint32_t packo(float lo, float hi) {
-  uint32_t w = pack2<T>(lo, hi);
-  asm("" : "+v"(w));
-  return w;
-}
-template <typename T> struct One;      // 1.0 in the storage type
-template <> struct One<bf16_t> { static constexpr uint32_t v = 0x3f80u; };
-template <> struct One<f16_t> { static constexpr uint32_t v = 0x3c00u; };
-
-// the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2]: a vector-ALU move, no LDS crossbar)
-__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
-// v of lane l % 32 and of lane 32 + l % 32, in every lane (v_permlane32_swap)
-__device__ __forceinline__ void both_halves(float v, float& lower, float& upper) {
-  const cs_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  lower = __uint_as_float(r[0]); upper = __uint_as_float(r[1]);
-}
-
-constexpr int PIXB = 48;          // bytes of one pixel: 24 channels x 2
 constexpr int KS_MAX = 16;        // K-steps of 16 per 3x3 layer: 14 (27 k-groups + the bias group); the staged image has room for 16
 constexpr int AUX_BYTES = 16 + 3 * 1024;      // behind the rings: the [1, 1, 1, 0 ...] vector, the output layer's two A fragments, the input layer's
 
@@ -127,50 +73,6 @@ struct CsP {
   int BH, nb, VB;               // band height, bands per image, virtual rows per band (BH + 8)
   int units;                    // N * n_strips * nb
 };
-
-struct Unit { int b, yb0, yb1, xs, xe, fx0; };
-
-__device__ __forceinline__ void decode_unit(const CsP& p, int u, Unit& U) {
-  const int j = u % p.nb, t = u / p.nb;
-  const int st = t % p.n_strips;
-  U.b = t / p.n_strips;
-  U.yb0 = j * p.BH; U.yb1 = min(p.H, U.yb0 + p.BH);
-  U.xs = st * p.SO; U.xe = min(p.W, U.xs + p.SO);
-  U.fx0 = p.n_strips > 1 ? U.xs - 4 : 0;
-}
-
-// Position of a stage in the workgroup's stream of virtual rows: unit index relative to the workgroup's first unit (negative while the
-// pipeline fills) and the row inside the unit's VB virtual rows.
-struct Cursor {
-  int urel, i;
-  Unit U;
-  __device__ __forceinline__ void init(const CsP& p, int u0, int nunits, int V) {
-    urel = V >= 0 ? V / p.VB : -1 - ((-V - 1) / p.VB);
-    i = V - urel * p.VB;
-    U = Unit{0, 0, 0, 0, 0, 0};
-    if (urel >= 0 && urel < nunits) decode_unit(p, u0 + urel, U);
-  }
-  __device__ __forceinline__ void advance(const CsP& p, int u0, int nunits, int rows) {
-    i += rows;
-    while (i >= p.VB) {
-      i -= p.VB;
-      ++urel;
-      if (urel >= 0 && urel < nunits) decode_unit(p, u0 + urel, U);
-    }
-  }
-};
-
-__device__ __forceinline__ int sfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-__device__ __forceinline__ int posmod(int v, int d) { const int m = v % d; return m < 0 ? m + d : m; }
-
-// fp32 -> three storage-type terms whose sum is the value to 24 bits (hi + mid + lo); term e of the split
-template <typename T> __device__ __forceinline__ float split3(float v, int e) {
-  const float hi = Elem<T>::to_f32(Elem<T>::from_f32(v));
-  const float mid = Elem<T>::to_f32(Elem<T>::from_f32(v - hi));
-  const float lo = Elem<T>::to_f32(Elem<T>::from_f32(v - hi - mid));
-  return e == 0 ? hi : e == 1 ? mid : lo;
-}
 
 // A operands, staged once per workgroup in LDS.  3x3 layers (over the ring area, before it is zeroed): image [layer][K-step c][lane] of 16
 // bytes; lane = (m = lane % 32 = output channel, h = lane / 32), k-group g = 2c + h:
@@ -561,21 +463,6 @@ __global__ __launch_bounds__(1024) void compose_stream_fwd_kernel(const CsP p) {
 #undef CS_ROLE
 }
 
-struct DevInfo { int cus; bool attr[8]; };
-DevInfo g_dev[16] = {};
-
-int device_cus() {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (g_dev[dev].cus == 0) {
-    int c = 0;
-    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
-    g_dev[dev].cus = c;
-  }
-  return g_dev[dev].cus;
-}
-
 }  // namespace
 
 // Geometry of a launch (exposed for tests / tools through dd_compose_stream_plan): frame width, rows per step, strips, bands.
@@ -620,27 +507,21 @@ int dd_compose_stream_fwd_launch(const dd_compose_args* a, hipStream_t s) {
   p.ld_small = a->ld_small; p.ld_fine = a->ld_fine; p.ld_out = a->ld_out;
   p.N = a->N; p.H = a->H; p.W = a->W;
   DD_REQUIRE((long)a->N * a->H * a->W < (1l << 31) / 64, "dd_compose_net_fwd: N * H * W = %ld pixels exceed the 32-bit offsets of the kernel", (long)a->N * a->H * a->W);
-  const int cus = device_cus();
+  const int cus = dd_device_cus();
   int g8[8];
   if (dd_compose_stream_plan(a->N, a->H, a->W, cus, g8) != DD_OK) return DD_ERR_INVALID;
   p.FW = g8[0]; p.R = g8[1]; p.TPR = g8[2]; p.n_strips = g8[3]; p.SO = g8[4]; p.BH = g8[5]; p.nb = g8[6]; p.VB = g8[7];
   p.units = a->N * p.n_strips * p.nb;
   const int grid = p.units < cus ? p.units : cus;
   const int lds = (12 * p.R + 10) * (p.FW + 2) * PIXB + AUX_BYTES;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-#define CS_LAUNCH(T, SV, IDX)                                                                                                        \
-  do {                                                                                                                               \
-    if (!g_dev[dev].attr[IDX]) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_stream_fwd_kernel<T, SV, R1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      g_dev[dev].attr[IDX] = true;                                                                                                   \
-    }                                                                                                                                \
-    hipLaunchKernelGGL((compose_stream_fwd_kernel<T, SV, R1>), dim3(grid), dim3(1024), lds, s, p);                                    \
+#define CS_LAUNCH(T, SV, R1)                                                                          \
+  do {                                                                                                \
+    dd_allow_max_lds(reinterpret_cast<const void*>(compose_stream_fwd_kernel<T, SV, R1>));            \
+    hipLaunchKernelGGL((compose_stream_fwd_kernel<T, SV, R1>), dim3(grid), dim3(1024), lds, s, p);    \
   } while (0)
-#define CS_LAUNCH_R(T, SV, IDX) do { if (p.R == 1) { constexpr bool R1 = true; CS_LAUNCH(T, SV, IDX); } else { constexpr bool R1 = false; CS_LAUNCH(T, SV, IDX + 4); } } while (0)
-  if (a->dtype == DD_BF16) { if (save) CS_LAUNCH_R(bf16_t, true, 0); else CS_LAUNCH_R(bf16_t, false, 1); }
-  else { if (save) CS_LAUNCH_R(f16_t, true, 2); else CS_LAUNCH_R(f16_t, false, 3); }
+#define CS_LAUNCH_R(T, SV) do { if (p.R == 1) CS_LAUNCH(T, SV, true); else CS_LAUNCH(T, SV, false); } while (0)
+  if (a->dtype == DD_BF16) { if (save) CS_LAUNCH_R(bf16_t, true); else CS_LAUNCH_R(bf16_t, false); }
+  else { if (save) CS_LAUNCH_R(f16_t, true); else CS_LAUNCH_R(f16_t, false); }
 #undef CS_LAUNCH_R
 #undef CS_LAUNCH
   DD_LAUNCH_CHECK();

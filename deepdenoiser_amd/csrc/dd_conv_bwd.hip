@@ -375,23 +375,13 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 }
 
 static int bwd_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return dd_device_cus();
 }
 
 template <typename T, bool MASK, bool ACCUM>
 int launch_bwd_flags(const BwdP& p, hipStream_t stream) {
   const size_t lds = 2 * (size_t)BW_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<T, MASK, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_bwd_kernel<T, MASK, ACCUM>));
   const long blocks = (long)p.nblk * p.nblk_co * p.ksplit;
   hipLaunchKernelGGL((conv_bwd_kernel<T, MASK, ACCUM>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();

@@ -790,7 +790,6 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvP p) {
   }
 }
 
-int g_num_cus = 0;
 
 // Persistent grid: at most `slots` workgroups, a multiple of the channel-block count and -- when that idles under 7 % of the slots and
 // every XCD still gets work -- of 8 * nblk, which turns on the XCD-aware tile assignment (tile_walk).
@@ -813,18 +812,9 @@ int launch(const ConvP& p, int nslabs, hipStream_t stream) {
   const size_t patch = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW;
   const size_t wb = (size_t)NT * 16 * DD_LDS_ROW;
   const size_t lds = patch + (RESIDENT ? (size_t)nslabs * wb : 2 * wb);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, NT, HALO, RESIDENT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  if (g_num_cus == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_igemm_kernel<T, NT, HALO, RESIDENT>));
   const int per_cu = (int)((160 * 1024) / lds) >= 2 ? 2 : 1;   // two resident workgroups overlap each other's memory phases
-  long wgs = grid_size((long)g_num_cus * per_cu, p);
+  long wgs = grid_size((long)dd_device_cus() * per_cu, p);
   hipLaunchKernelGGL((conv_igemm_kernel<T, NT, HALO, RESIDENT>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -840,17 +830,8 @@ static size_t ws_weight_bytes(const ConvP& p, int nt) {
 template <typename T, int NT, bool HALO>
 int launch_ws(const ConvP& p, int nslabs, hipStream_t stream) {
   const size_t lds = (size_t)PatchDim<HALO>::NPIX * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW + ws_weight_bytes(p, NT) + NT * 16 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, NT, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  if (g_num_cus == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus <= 0) g_num_cus = 256;
-  }
-  long wgs = grid_size((long)g_num_cus, p);
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_igemm_ws_kernel<T, NT, HALO>));
+  long wgs = grid_size((long)dd_device_cus(), p);
   hipLaunchKernelGGL((conv_igemm_ws_kernel<T, NT, HALO>), dim3((unsigned)wgs), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;

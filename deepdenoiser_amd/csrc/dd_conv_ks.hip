@@ -284,13 +284,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const KsMulti m) {
 }
 
 static int ks_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return dd_device_cus();
 }
 
 }  // namespace
@@ -351,12 +345,10 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
   for (int i = ns; i < KS_MAX_SUB; ++i) m.sub[i] = KsSub{0, 1, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == DD_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ks_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(conv_ks_kernel<bf16_t>));
     hipLaunchKernelGGL(conv_ks_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)ns), dim3(512), 2 * (size_t)KS_BUF, s, m);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ks_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(conv_ks_kernel<f16_t>));
     hipLaunchKernelGGL(conv_ks_kernel<f16_t>, dim3((unsigned)gx, (unsigned)ns), dim3(512), 2 * (size_t)KS_BUF, s, m);
   }
   DD_LAUNCH_CHECK();

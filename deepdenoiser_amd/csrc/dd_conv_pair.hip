@@ -229,19 +229,12 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairP a) {
 }
 
 int pr_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return dd_device_cus();
 }
 
 template <typename T>
 void pair_launch(const PairP& p, hipStream_t s) {
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pair_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_pair_kernel<T>));
   hipLaunchKernelGGL(conv_pair_kernel<T>, dim3((unsigned)p.ksplit), dim3(512), 2 * (size_t)PR_IBUF + PR_MBYTES, s, p);
 }
 

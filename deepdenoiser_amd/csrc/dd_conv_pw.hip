@@ -304,13 +304,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const PwP a) {
 }
 
 int pw_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return dd_device_cus();
 }
 
 bool pw_enabled() {
@@ -342,12 +336,10 @@ long pw_min_pixels() {
 template <typename T, int CTN>
 void pw_launch_ctn(const PwP& p, bool in_relu, unsigned grid, hipStream_t s) {
   if (in_relu) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<T, CTN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(conv_pw_kernel<T, CTN, true>));
     hipLaunchKernelGGL((conv_pw_kernel<T, CTN, true>), dim3(grid), dim3(512), 2 * (size_t)PW_BUF, s, p);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<T, CTN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(conv_pw_kernel<T, CTN, false>));
     hipLaunchKernelGGL((conv_pw_kernel<T, CTN, false>), dim3(grid), dim3(512), 2 * (size_t)PW_BUF, s, p);
   }
 }
@@ -565,13 +557,11 @@ template <typename T, int CTM, int CTN>
 void wgrad_pw_launch_cfg(const PwgP& p, unsigned grid, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(CTM + (CTN + 1) / 2) * 64 * DD_LDS_ROW;
   if (p.g9_cp) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, true>));
     hipLaunchKernelGGL((wgrad_pw_kernel<T, CTM, CTN, true>), dim3(grid), dim3(512), lds, s, p);
     return;
   }
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+  dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, false>));
   hipLaunchKernelGGL((wgrad_pw_kernel<T, CTM, CTN, false>), dim3(grid), dim3(512), lds, s, p);
 }
 

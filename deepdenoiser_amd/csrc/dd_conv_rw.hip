@@ -400,22 +400,12 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
 }
 
 static int rw_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return dd_device_cus();
 }
 
 template <typename T, int KC, int AUX, bool ACCUM>
 static void rw_launch(const RwP& p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw_kernel<T, KC, AUX, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_rw_kernel<T, KC, AUX, ACCUM>));
   hipLaunchKernelGGL((conv_rw_kernel<T, KC, AUX, ACCUM>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(512), 2 * (size_t)RW_BUF, stream, p);
 }
 template <typename T, int KC>
@@ -449,11 +439,7 @@ bool dd_conv_rw_eligible(const dd_conv_args* a) {
 
 template <typename T, int KC, int NW = 8>
 static void rw8_launch(const RwP& p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC, NW>));
   hipLaunchKernelGGL((conv_rw8_kernel<T, KC, NW>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(NW * 64), 2 * (size_t)RfGeo<KC>::BUF, stream, p);
 }
 

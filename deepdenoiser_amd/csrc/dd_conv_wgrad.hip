@@ -662,11 +662,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 template <typename T, bool IN_RELU, int MODE>
 static void launch_dma_mode(const WgradP& p, long blocks, hipStream_t stream) {
   const size_t lds = 2 * (size_t)WgLds<MODE != 2>::BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<T, IN_RELU, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_dma_kernel<T, IN_RELU, MODE>));
   hipLaunchKernelGGL((wgrad_dma_kernel<T, IN_RELU, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
 }
 
@@ -707,11 +703,7 @@ template <typename T, int TAPS>
 int launch(const WgradP& p, hipStream_t stream) {
   constexpr int PH = (TAPS == 9) ? DD_TILE + 2 : DD_TILE;
   const size_t lds = (size_t)PH * PH * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_kernel<T, TAPS>), 96 * 1024);
   const long blocks = (long)p.ksplit * p.mslices * p.nslices;
   hipLaunchKernelGGL((wgrad_kernel<T, TAPS>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   DD_LAUNCH_CHECK();

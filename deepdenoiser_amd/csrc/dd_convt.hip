@@ -365,27 +365,12 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
 }
 
 static int ct_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
+  return dd_device_cus();
 }
 
 template <typename K>
 static void ct_launch(K kernel, const CtP& p, size_t lds, hipStream_t stream) {
-  // (the attribute is set once per kernel instantiation: a small set, looked up by function address)
-  static const void* done[32];
-  static int n_done = 0;
-  const void* f = reinterpret_cast<const void*>(kernel);
-  bool seen = false;
-  for (int i = 0; i < n_done; ++i) seen = seen || done[i] == f;
-  if (!seen) {
-    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (n_done < 32) done[n_done++] = f;
-  }
+  dd_allow_max_lds(reinterpret_cast<const void*>(kernel));
   hipLaunchKernelGGL(kernel, dim3((unsigned)p.nwg), dim3(512), lds, stream, p);
 }
 

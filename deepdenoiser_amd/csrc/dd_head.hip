@@ -653,15 +653,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
   HPH(7);
 }
 
-int g_head_cus = 0;
-static int head_cus() {
-  if (g_head_cus == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&g_head_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_head_cus <= 0) g_head_cus = 256;
-  }
-  return g_head_cus;
-}
+static int head_cus() { return dd_device_cus(); }
 
 template <typename T, int KS, int NCH>
 int launch_head(const HeadP& p, bool backward, hipStream_t s) {
@@ -675,12 +667,8 @@ int launch_head(const HeadP& p, bool backward, hipStream_t s) {
   } else {
     constexpr int STRIP = 32 * (3 * 64 + NCH * 64);
     const size_t lds = BWD_WAVES * (size_t)STRIP + (size_t)(HeadDim<KS>::NT * NCH + NCH * 2 + 4 * HeadDim<KS>::NT) * 1024;
-    static bool set = false;
-    if (!set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      set = true;
-    }
+    dd_allow_max_lds(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, false>));
+    dd_allow_max_lds(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, true>));
     long wgs = (long)head_cus();                       // persistent: one flush of the gradient tiles per workgroup
     const long steps = (p.npix + 31) / 32;
     if (wgs * BWD_WAVES > steps) wgs = (steps + BWD_WAVES - 1) / BWD_WAVES;

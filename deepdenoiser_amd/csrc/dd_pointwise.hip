@@ -7,6 +7,39 @@
 
 // ------------------------------------------------------------------------------------------------ errors (dd_version: csrc/dd_version.hip)
 static thread_local char g_err[512] = "";
+#include <mutex>
+#include <set>
+#include <utility>
+
+namespace {
+std::mutex g_dev_mutex;
+int g_dev_cus[64];
+std::set<std::pair<int, const void*>> g_dev_lds;
+int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev < 0 || dev >= 64 ? 0 : dev;
+}
+}  // namespace
+
+int dd_device_cus() {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  if (g_dev_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_dev_cus[dev] = n;
+  }
+  return g_dev_cus[dev];
+}
+
+void dd_allow_max_lds(const void* kernel, int bytes) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  if (g_dev_lds.insert(std::make_pair(dev, kernel)).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 void dd_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -545,8 +578,7 @@ extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, i
   const int tiles_x = dd_ceil_div(W, 16), tiles_y = dd_ceil_div(H, 16);
   const unsigned grid = (unsigned)((long)n_tuples * B * tiles_x * tiles_y);
   DD_DISPATCH_DTYPE(dtype, T, {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_input_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
+    dd_allow_max_lds(reinterpret_cast<const void*>(assemble_input_kernel<T>), 96 * 1024);
     hipLaunchKernelGGL(assemble_input_kernel<T>, dim3(grid), dim3(256), lds, S(stream), table, n_entries, (T*)dst, ld, c_pad, B, H, W, tiles_x, tiles_y);
   });
   DD_LAUNCH_CHECK();

@@ -519,7 +519,7 @@ class Graph:
             cj = c0 + j * f
             assert lay.cin == cj and lay.cout == f and lay.k == 3
             self.conv(buf.view(0, cj), lay, relu=False, in_relu=True, out=buf.view(cj, f, relu=False), no_backward=gather)
-        if not gather:
+        if not gather or not bool(getattr(self, "training", True)):      # the stacked images below only feed the backward
             return c0 + n * f
         ps, lib, code = self.params, self.lib, self.code
 
@@ -692,7 +692,8 @@ class Graph:
         # ... and so does the BACKWARD (round 3): with the output gradient rearranged by output parity (dd_space_to_depth2) the data gradient is a
         # 2 x 2-tap conv on the input grid (dd_conv3x3_ks mode 6) and the filter gradient one GEMM over nine shifted channel windows
         # (dd_convt3_wgrad): no zero-stuffed tensor, no 4x-redundant MACs.  DD_CONVT3_S2D_BWD=0: differentiate the zero-stuffed form instead.
-        s2d_bwd = (parity and x.ld % 8 == 0 and x.ch0 % 8 == 0 and layer.cin % 4 == 0 and os.environ.get("DD_CONVT3_S2D_BWD", "1") != "0")
+        s2d_bwd = (parity and bool(getattr(self, "training", True)) and x.ld % 8 == 0 and x.ch0 % 8 == 0 and layer.cin % 4 == 0
+                   and os.environ.get("DD_CONVT3_S2D_BWD", "1") != "0")      # (the s2d image only feeds the backward)
         need_z = (not parity) or (bool(getattr(self, "training", True)) and not s2d_bwd)
         z = self.tensor(x.B, 2 * x.H, 2 * x.W, x.C, requires_grad=x.requires_grad) if need_z else None
         if s2d_bwd:

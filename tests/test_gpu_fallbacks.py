@@ -23,6 +23,9 @@ CASES = {
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_op_parity_with_library_paths_switched_off(name):
+    import torch
+    if not torch.cuda.is_available():      # the child would skip every test and report none passed (plain `pytest tests` on a box without a GPU)
+        pytest.skip("no GPU")
     env_extra, expr = CASES[name]
     env = dict(os.environ, **env_extra)
     env.pop("DD_PARITY_REPORT", None)
