@@ -167,9 +167,27 @@ def _conv_roofline(prog, peak):
     times = prog.profile_ops(repeats=2)
     convs = {k: v for k, v in times.items() if k in ("conv_igemm", "conv_bwd", "conv_wgrad", "convt") and v[1] > 0}
     ms, fl = sum(v[1] for v in convs.values()), sum(v[2] for v in convs.values())
-    return {"bound": "mfma", "kernel": "all MFMA conv launches of the step", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+    roof = {"bound": "mfma", "kernel": "all MFMA conv launches of the step", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": fl / (ms * 1e-3) / 1e12 / peak, "conv_ms_per_step": round(ms, 3), "all_launches_ms_per_step": round(sum(v[1] for v in times.values()), 3),
             "algorithmic_gflop_per_step": fl / 1e9, "families_ms": {k: round(v[1], 3) for k, v in times.items()}}
+    # which roof binds: algorithmic bytes of the forward / data-gradient launches (every input and output element once, plus the output-shaped
+    # operands a launch reads: mask, residual, accumulated gradient) against their flops.  Below the ridge (peak / 8 TB/s = 312 flop/B in
+    # bf16) the launches are HBM-bound and `bound`, `achieved`, `peak`, `frac` are restated in bytes; the MFMA view stays in `mfma_view`.
+    recs = prog.g.conv_records
+    if recs and "conv_igemm" in times and times["conv_igemm"][1] > 0:
+        esz = 4 if prog.arch.dtype == "f32" else 2
+        by = sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r["extra_reads"])) * esz for r in recs)
+        fam_fl, fam_ms = times["conv_igemm"][2], times["conv_igemm"][1]
+        intensity, ridge = fam_fl / by, 1e3 * peak / PEAK_HBM_GBS
+        hbm = {"achieved": by / (fam_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / (fam_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+               "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "launch_family": "conv_igemm (forward + data gradients)",
+               "ms_per_step": round(fam_ms, 3), "algorithmic_bytes_per_step": by}
+        if intensity < ridge:
+            roof["mfma_view"] = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
+            roof.update({"bound": "hbm", "kernel": hbm["launch_family"] + " launches of the step", "achieved": hbm["achieved"], "peak": hbm["peak"],
+                         "unit": "GB/s", "frac": hbm["frac"]})
+        roof["hbm_view"] = hbm
+    return roof
 
 
 def extras(device, B, H, W):

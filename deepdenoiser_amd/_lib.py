@@ -23,7 +23,7 @@ SYMBOLS = (
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
     "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_assemble_input", "dd_conv3x3_bwd", "dd_convt2x2_fwd", "dd_convt2x2_bwd", "dd_conv3x3_ks",
-    "dd_conv_pw_count", "dd_wgrad_pw_count", "dd_space_to_depth2", "dd_convt3_wgrad", "dd_conv3x3_pair", "dd_compose_stream_plan",
+    "dd_conv_pw_count", "dd_wgrad_pw_count", "dd_space_to_depth2", "dd_convt3_wgrad", "dd_conv3x3_pair", "dd_compose_stream_plan", "dd_compose_bwd_scratch_bytes",
 )
 
 
@@ -159,7 +159,8 @@ class ComposeBwdArgs(C.Structure):
                 ("d_small", C.c_void_p), ("ld_dsmall", C.c_int), ("accumulate_small", C.c_int), ("d_fine", C.c_void_p), ("ld_dfine", C.c_int),
                 ("dw_in", C.c_void_p), ("db_in", C.c_void_p), ("dw_res", C.c_void_p * 4), ("db_res", C.c_void_p * 4),
                 ("dw_out", C.c_void_p), ("db_out", C.c_void_p),
-                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_long)]
 
 
 class HeadArgs(C.Structure):
@@ -266,6 +267,8 @@ def load():
     lib.dd_compose_net_fwd.argtypes = [C.POINTER(ComposeArgs), vp]
     lib.dd_compose_net_bwd.argtypes = [C.POINTER(ComposeBwdArgs), vp]
     lib.dd_compose_stream_plan.argtypes = [i, i, i, i, C.POINTER(C.c_int)]
+    lib.dd_compose_bwd_scratch_bytes.argtypes = [i, i, i]
+    lib.dd_compose_bwd_scratch_bytes.restype = C.c_long
     lib.dd_assemble_input.argtypes = [vp, i, i, vp, i, i, i, i, i, i, vp]
     lib.dd_kpcn_head_fwd.argtypes = [C.POINTER(HeadArgs), vp]
     lib.dd_kpcn_head_bwd.argtypes = [C.POINTER(HeadArgs), vp]

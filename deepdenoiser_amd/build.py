@@ -14,9 +14,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["dd_conv_igemm.hip", "dd_conv_wgrad.hip", "dd_pointwise.hip", "dd_compose.hip", "dd_head.hip", "dd_conv_bwd.hip", "dd_convt.hip",
-           "dd_conv_rw.hip", "dd_conv_ks.hip", "dd_conv_pw.hip", "dd_conv_pair.hip", "dd_compose_stream.hip"]
+           "dd_conv_rw.hip", "dd_conv_ks.hip", "dd_conv_pw.hip", "dd_conv_pair.hip", "dd_compose_stream.hip", "dd_compose_stream_bwd.hip"]
 VERSION_SRC = "dd_version.hip"
-HEADERS = ["dd_common.h", os.path.join("..", "..", "include", "dd_hip.h")]
+HEADERS = ["dd_common.h", "dd_compose_stream.h", os.path.join("..", "..", "include", "dd_hip.h")]
 LIB = os.path.join(HERE, "libdd_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Kernels that must not use scratch memory.  (1) Kernels whose long-lived accumulators are updated by in-place inline-asm MFMAs (no hazard

@@ -894,6 +894,9 @@ __global__ __launch_bounds__(BWD_THREADS) void compose_bwd_kernel(const ComposeB
 }  // namespace
 
 int dd_compose_stream_fwd_launch(const dd_compose_args* a, hipStream_t s);      // csrc/dd_compose_stream.hip
+int dd_compose_stream_bwd_data_launch(const dd_compose_bwd_args* a, void* scratch, hipStream_t s);      // csrc/dd_compose_stream_bwd.hip
+int dd_compose_stream_wgrad_launch(const dd_compose_bwd_args* a, void* scratch, hipStream_t s);
+extern "C" long dd_compose_bwd_scratch_bytes(int N, int H, int W);
 
 extern "C" int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream) {
   DD_REQUIRE(a && a->small && a->fine && a->out && a->w_in && a->b_in && a->w_out && a->b_out, "dd_compose_net_fwd: null pointer");
@@ -945,6 +948,20 @@ extern "C" int dd_compose_net_bwd(const dd_compose_bwd_args* a, dd_stream stream
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_compose_net_bwd: storage dtype must be DD_BF16 or DD_F16");
   DD_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->H % 2 == 0 && a->W % 2 == 0, "dd_compose_net_bwd: H=%d W=%d must be positive and even", a->H, a->W);
   DD_REQUIRE(a->ld_small >= 3 && a->ld_fine >= 3 && a->ld_dout >= 3 && a->ld_dsmall >= 3 && a->ld_dfine >= 3 && a->ld_wl >= 1, "dd_compose_net_bwd: bad ld");
+  if (a->scratch) {
+    // round 4: two row-streaming launches (csrc/dd_compose_stream_bwd.hip); DD_COMPOSE_STREAM_BWD=0 keeps the 16x16-tile kernel below
+    static const bool stream_bwd = !(getenv("DD_COMPOSE_STREAM_BWD") && getenv("DD_COMPOSE_STREAM_BWD")[0] == '0');
+    bool rows24 = true;
+    for (int i = 0; i < 5; ++i) rows24 = rows24 && a->ld_act[i] == 24;
+    if (stream_bwd && rows24 && (long)a->N * a->H * a->W < (1l << 31) / 64) {
+      DD_REQUIRE(a->scratch_bytes >= dd_compose_bwd_scratch_bytes(a->N, a->H, a->W) && ((uintptr_t)a->scratch % 16) == 0,
+                 "dd_compose_net_bwd: scratch of %ld bytes, %ld needed (16-byte aligned)", a->scratch_bytes, dd_compose_bwd_scratch_bytes(a->N, a->H, a->W));
+      hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+      const int rc = dd_compose_stream_bwd_data_launch(a, a->scratch, st);
+      if (rc != DD_OK) return rc;
+      return dd_compose_stream_wgrad_launch(a, a->scratch, st);
+    }
+  }
   ComposeBwdP p;
   p.small = a->small; p.fine = a->fine; p.gout = a->dout; p.wl = a->wl;
   for (int i = 0; i < 5; ++i) { p.act[i] = a->act[i]; p.ld_act[i] = a->ld_act[i]; }

@@ -33,7 +33,8 @@ struct CbP {
   const void* wl;
   const float* w_in; const float* w_res[4]; const float* w_out;
   float* d_small; float* d_fine;
-  void* g[4];                       // scratch [pixel][24]: dz1, dc1, d a2, dc3
+  void* g[5];                       // scratch [pixel][24]: dz1, dc1, d a2, dc3, dA
+  void* x0;                         // scratch [pixel][8]: the packed net input [up(small) | fine | 1 | 0]
   void* dz6;                        // scratch [pixel]
   int ld_small, ld_fine, ld_gout, ld_act[4], ld_wl, ld_dsmall, ld_dfine, acc_small;
   int N, H, W;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
   // stage 0 (LAYER 0 waves): its own cursor; operands requested one step ahead
   Cursor c0;
   int o0 = 0, ybase0 = 0, pixb0 = 0, pix0 = 0;
-  bool col_in0 = false, col_own0 = false, cols_all_in0 = false, in0 = false, own0 = false;
+  bool col_in0 = false, col_own0 = false, cols_all_in0 = false, in0 = false, own0 = false, odd0 = false;
   float g0[3] = {0.f, 0.f, 0.f}, sm0[3] = {0.f, 0.f, 0.f}, f0[3] = {0.f, 0.f, 0.f}, wl0 = 0.f;
   const int s0_end = has_task ? (total_rows - r + R - 1) / R : 0;
   auto load_s0 = [&](int s_next) {
@@ -140,6 +141,7 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
       in0 = row_in && col_in0;
       own0 = in0 && col_own0 && y >= c0.U.yb0 && y < c0.U.yb1;
       const int cy = row_in ? y : 0;
+      odd0 = (cy & 1) != 0;
       pix0 = pixb0 + cy * W;
       const int cx = pix0 - (c0.U.b * H + cy) * W;
       const float* gp = p.gout + (size_t)pix0 * p.ld_gout;
@@ -210,12 +212,15 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
     // ------------------------------------------------------------------------------------------ stage 0: dz6 and dA = w_out dz6
     if (LAYER == 0) {
       if (s < s0_end) {
-        float low[3], dwv = 0.f;
+        float low[3], f_own[3], dwv = 0.f;
+        const bool odd_row = odd0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float pair = f0[c] + dpp_xor1(f0[c]);
-          float p_lo, p_hi;
+          float p_lo, p_hi, f_lo, f_hi;
           both_halves(pair, p_lo, p_hi);
+          both_halves(f0[c], f_lo, f_hi);
+          f_own[c] = odd_row ? f_hi : f_lo;                   // k-half h fetched row (y & ~1) + h of the block
           low[c] = 0.25f * (p_lo + p_hi);
           dwv += g0[c] * (sm0[c] - low[c]);
         }
@@ -225,15 +230,24 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
         const uint32_t dzp = pack2<T>(dz6, 0.f);
         float unused;
         unpack2<T>(dzp, dz6, unused);
-        if (own0 && h == 0) reinterpret_cast<uint16_t*>(p.dz6)[pix0] = (uint16_t)(dzp & 0xffffu);
+        if (own0 && h == 0) {
+          reinterpret_cast<uint16_t*>(p.dz6)[pix0] = (uint16_t)(dzp & 0xffffu);
+          // the packed net input of the pixel, as the layer-wise path stores it (+ a ones channel: the bias row of dW1), for the weight gradients
+          float fo[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) fo[c] = f_own[c];
+          reinterpret_cast<uint4*>(p.x0)[pix0] = uint4{pack2<T>(sm0[0], sm0[1]), pack2<T>(sm0[2], fo[0]), pack2<T>(fo[1], fo[2]), One<T>::v};
+        }
         const float* wo = reinterpret_cast<const float*>(aux + 2048);
         char* o = rin + o0 + wr;
+        char* gd = reinterpret_cast<char*>(p.g[4]) + ((size_t)pix0 * 24 + 4 * h) * 2;
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wo + 8 * b + 4 * h);
           uint2 pk;
           pk.x = pack2<T>(wv[0] * dz6, wv[1] * dz6); pk.y = pack2<T>(wv[2] * dz6, wv[3] * dz6);
           *reinterpret_cast<uint2*>(o + b * 16) = pk;
+          if (own0) *reinterpret_cast<uint2*>(gd + b * 16) = pk;
         }
       }
       c0.i += R;
@@ -287,7 +301,12 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
       const char* mp = reinterpret_cast<const char*>(p.act[MASK_ACT]) + ((size_t)pix * p.ld_act[MASK_ACT] + 4 * h) * 2;
       uint2 mk[3];
 #pragma unroll
+#ifdef CB_EXP_NO_MASK_LOADS
+      for (int b = 0; b < 3; ++b) mk[b] = uint2{0x3f803f80u, (unsigned)pix};
+      (void)mp;
+#else
       for (int b = 0; b < 3; ++b) mk[b] = *reinterpret_cast<const uint2*>(mp + b * 16);
+#endif
       float gt[3] = {0.f, 0.f, 0.f}, wlt = 0.f;
       if (FINAL) {
         const float* gp = p.gout + (size_t)pix * p.ld_gout;
@@ -325,7 +344,11 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
 #pragma unroll
         for (int b = 0; b < 3; ++b) { pk[b].x = inside ? pk[b].x : 0u; pk[b].y = inside ? pk[b].y : 0u; }
       }
+#ifdef CB_EXP_NO_G_STORES
+      if (own && pk[0].x == 0x12345u) {
+#else
       if (own) {                                             // for the weight-gradient launch
+#endif
         char* gp = reinterpret_cast<char*>(p.g[3 - LAYER]) + ((size_t)pix * 24 + 4 * h) * 2;
 #pragma unroll
         for (int b = 0; b < 3; ++b) *reinterpret_cast<uint2*>(gp + b * 16) = pk[b];
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(1024) void compose_stream_bwd_kernel(const CbP p) {
 int dd_compose_stream_plan(int N, int H, int W, int cus, int* out8);
 
 // scratch bytes dd_compose_net_bwd needs for an [N, H, W] launch: four 24-channel gradient tensors and dz6, in the storage type
-extern "C" long dd_compose_bwd_scratch_bytes(int N, int H, int W) { return ((long)N * H * W * (4 * 24 + 8)) * 2; }
+extern "C" long dd_compose_bwd_scratch_bytes(int N, int H, int W) { return (long)N * H * W * (5 * 48 + 16 + 16); }
 
 int dd_compose_stream_bwd_data_launch(const dd_compose_bwd_args* a, void* scratch, hipStream_t s) {
   CbP p;
@@ -447,8 +470,9 @@ int dd_compose_stream_bwd_data_launch(const dd_compose_bwd_args* a, void* scratc
   for (int l = 0; l < 4; ++l) p.w_res[l] = a->w_res[l];
   p.d_small = a->d_small; p.d_fine = a->d_fine;
   const long npix = (long)a->N * a->H * a->W;
-  for (int i = 0; i < 4; ++i) p.g[i] = reinterpret_cast<char*>(scratch) + (size_t)i * npix * 48;
-  p.dz6 = reinterpret_cast<char*>(scratch) + (size_t)4 * npix * 48;
+  for (int i = 0; i < 5; ++i) p.g[i] = reinterpret_cast<char*>(scratch) + (size_t)i * npix * 48;
+  p.x0 = reinterpret_cast<char*>(scratch) + (size_t)5 * npix * 48;
+  p.dz6 = reinterpret_cast<char*>(scratch) + (size_t)npix * (5 * 48 + 16);
   p.ld_small = a->ld_small; p.ld_fine = a->ld_fine; p.ld_gout = a->ld_dout; p.ld_wl = a->ld_wl; p.ld_dsmall = a->ld_dsmall; p.ld_dfine = a->ld_dfine;
   p.acc_small = a->accumulate_small;
   p.N = a->N; p.H = a->H; p.W = a->W;
@@ -488,17 +512,15 @@ namespace {
 
 constexpr int WG_SW = 64;                    // strip width
 constexpr int WG_GROW = 4096, WG_AROW = 3072; // bytes of a gradient row in LDS (85 pixels: 1 halo + 64 + 1 halo + slack) / of an activation row
-constexpr int WG_WAVES = 14;
+constexpr int WG_WAVES = 12;
 
 struct CwP {
-  const float* small; const float* fine;
   const void* act[5];                       // a1, relu(r1), a2, relu(r3), a3   ([pixel][24])
-  const void* g[4];                         // dz1, dc1, d a2, dc3            ([pixel][24])
+  const void* g[5];                         // dz1, dc1, d a2, dc3, dA         ([pixel][24])
+  const void* x0;                           // [pixel][8]: the packed net input + ones channel
   const void* dz6;                          // [pixel]
   const void* zero16;                       // 16 bytes of zeros in global memory
-  const float* w_out;
   float* dw_in; float* db_in; float* dw_res[4]; float* db_res[4]; float* dw_out; float* db_out;
-  int ld_small, ld_fine;
   int N, H, W, strips, BH, nb, units;
 };
 
@@ -511,137 +533,139 @@ __device__ __forceinline__ void cw_dma_1k(const void* gptr, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory");
 }
 
+template <int N> __device__ __forceinline__ void cw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+// LDS map: gradient rings G[4 tensors][5 rows] (dc1, d a2, dc3, dA), activation rows A[4][3], a3 rows [3], dz1 rows [3], the packed net
+// input rows [3][64 px][16 B] and dz6 rows [3][64 px][2 B] (every block a DMA target: 1-KiB aligned)
+constexpr int CW_G_OFF = 0, CW_A_OFF = CW_G_OFF + 20 * WG_GROW, CW_A3_OFF = CW_A_OFF + 12 * WG_AROW, CW_Z1_OFF = CW_A3_OFF + 3 * WG_AROW;
+constexpr int CW_X0_OFF = CW_Z1_OFF + 3 * WG_AROW, CW_Z6_OFF = CW_X0_OFF + 3 * 1024, CW_LDS = CW_Z6_OFF + 3 * 1024;
+
 template <typename T>
 __global__ __launch_bounds__(WG_WAVES * 64) void compose_stream_wgrad_kernel(const CwP p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr uint32_t ONE = One<T>::v, ONE2 = ONE | (ONE << 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = sfl(tid >> 6);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  // LDS: gradient rings G[4 tensors][4 rows] (tensor 3 = dA, built here), activation rows A[4][2], a3 rows [2], dz1 rows [2] (DMA targets
-  // first: 1-KiB aligned), then the packed net input rows [2][64 px][16 B] and dz6 rows [2][66 px] as fp32
-  constexpr int G_OFF = 0, A_OFF = G_OFF + 16 * WG_GROW, A3_OFF = A_OFF + 8 * WG_AROW, Z1_OFF = A3_OFF + 2 * WG_AROW;
-  constexpr int X0_OFF = Z1_OFF + 2 * WG_AROW, Z6_OFF = X0_OFF + 2 * 1024, LDS_END = Z6_OFF + 2 * 512;
-  const int H = p.H, W = p.W, h2 = H >> 1, w2 = W >> 1;
+  const int H = p.H, W = p.W;
   const int G = gridDim.x, gb = blockIdx.x;
   const int u0 = (int)(((long)p.units * gb) / G), u1 = (int)(((long)p.units * (gb + 1)) / G);
 
-  // ---- roles
-  const int layer = wave < 12 ? wave / 3 : -1, dyi = wave < 12 ? wave % 3 : 1;       // layer index 0..3 = conv2d_1..4 (g tensor index layer + ... below)
-  f32x16_t acc[3];
+  // ---- roles: wave = (layer 0..3 = conv2d_1..4, tap row dyi); waves 0 and 1 also take the two 1x1 layers (acc[3])
+  const int layer = wave / 3, dyi = wave % 3;
+  f32x16_t acc[4];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   const int m = lane & 31, kh = lane >> 5, t16 = lane & 15, cblk = (lane >> 4) & 1;
   // lane part of a transposing fragment read: pixel (t16 >> 2) of a 4-pixel run, channels 16 cblk + 4 (t16 & 3) ..
   const unsigned tr_lane = (unsigned)((t16 >> 2) * PIXB + cblk * 32 + (t16 & 3) * 8);
   const bool ones_row = m == 24;
+  auto gslot = [](int row) { return (row + 10) % 5; };
+  auto aslot = [](int row) { return (row + 9) % 3; };
 
   for (int u = u0; u < u1; ++u) {
     const int j = u % p.nb, tq = u / p.nb, st = tq % p.strips, b = tq / p.strips;
     const int yb0 = j * p.BH, yb1 = min(H, yb0 + p.BH), xs = st * WG_SW;
-    // rows are fetched one step ahead: `fetch(y)` brings activation row y, a3 / dz1 / dz6 / x0 of row y and gradient row y + 1 of every tensor
-    auto fetch = [&](int y, bool first) {
-      // DMA pieces: 30 KiB-chunks per step (3 gradient tensors x 4 + 4 activations x 3 + a3 x 3 + dz1 x 3), dealt to the 14 waves
-      for (int c = wave; c < 30 + (first ? 24 : 0); c += WG_WAVES) {
-        int tensor, chunk, row, is_g;
-        if (c < 12) { is_g = 1; tensor = c >> 2; chunk = c & 3; row = y + 1; }                       // g[1..3] = dc1, d a2, dc3  (ring index tensor)
-        else if (c < 24) { is_g = 0; tensor = (c - 12) / 3; chunk = (c - 12) % 3; row = y; }           // act 0..3
-        else if (c < 27) { is_g = 0; tensor = 4; chunk = c - 24; row = y; }                            // a3
-        else if (c < 30) { is_g = 0; tensor = 5; chunk = c - 27; row = y; }                            // dz1
-        else { const int e = c - 30; is_g = 1; tensor = (e >> 2) % 3; chunk = e & 3; row = y - 1 + (e / 12); }   // first step of a unit: gradient rows y - 1, y
-        const int piece = chunk * 64 + lane;                 // 16-byte piece of the LDS row
-        const int px = piece / 3, part = piece - px * 3;
-        const int gx = is_g ? xs - 1 + px : xs + px;
-        const bool ok = (unsigned)row < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const char* base = is_g ? reinterpret_cast<const char*>(p.g[1 + tensor]) : tensor < 4 ? reinterpret_cast<const char*>(p.act[tensor])
-                           : tensor == 4 ? reinterpret_cast<const char*>(p.act[4]) : reinterpret_cast<const char*>(p.g[0]);
-        const char* src = ok ? base + ((size_t)((b * H + row) * W + gx) * 24) * 2 + part * 16 : reinterpret_cast<const char*>(p.zero16);
-        unsigned dst;
-        if (is_g) dst = lds0 + G_OFF + (tensor * 4 + (row & 3)) * WG_GROW + chunk * 1024;
-        else if (tensor < 4) dst = lds0 + A_OFF + (tensor * 2 + (row & 1)) * WG_AROW + chunk * 1024;
-        else if (tensor == 4) dst = lds0 + A3_OFF + (row & 1) * WG_AROW + chunk * 1024;
-        else dst = lds0 + Z1_OFF + (row & 1) * WG_AROW + chunk * 1024;
-        cw_dma_1k(src, dst);
+    // Rows arrive TWO steps ahead of their use (the step is shorter than an HBM round trip): `dma(y)` requests row y of the four activations,
+    // of a3, dz1, the packed net input and dz6, and row y + 1 of the four gradient tensors: 36 one-KiB pieces, 3 per wave.  A piece's
+    // lane-dependent part (source address at row 0, whether its pixel's column exists, destination) is worked out ONCE per unit: per step a
+    // piece costs a 64-bit add, two selects and the DMA instruction.
+    // (three named records, not an array: hipcc keeps arrays of such records in scratch memory)
+    struct Piece { const char* src; bool colok; unsigned dst; int isg, rowb; size_t rb; };
+    auto make_piece = [&](int c) {
+      Piece q;
+      int chunk, gx, part = 0;
+      const char* base;
+      size_t pxbytes = 48;
+      q.rb = (size_t)W * 48;
+      if (c < 16) {                                          // gradient rings 0..3 = g[1..4], 4 pieces each
+        const int tensor = c >> 2; chunk = c & 3;
+        const int piece = chunk * 64 + lane, px = (piece * 171) >> 9;      // (piece / 3 for piece < 256)
+        part = piece - px * 3; gx = xs - 1 + px;
+        base = reinterpret_cast<const char*>(p.g[1 + tensor]);
+        q.isg = 1; q.rowb = WG_GROW;
+        q.dst = lds0 + CW_G_OFF + tensor * 5 * WG_GROW + chunk * 1024;
+      } else if (c < 34) {                                   // activations 0..3, a3, dz1: 3 pieces each
+        const int tensor = (c - 16) / 3; chunk = (c - 16) % 3;
+        const int piece = chunk * 64 + lane, px = (piece * 171) >> 9;
+        part = piece - px * 3; gx = xs + px;
+        base = tensor < 5 ? reinterpret_cast<const char*>(p.act[tensor]) : reinterpret_cast<const char*>(p.g[0]);
+        q.isg = 0; q.rowb = WG_AROW;
+        q.dst = lds0 + chunk * 1024 + (tensor < 4 ? CW_A_OFF + tensor * 3 * WG_AROW : tensor == 4 ? CW_A3_OFF : CW_Z1_OFF);
+      } else if (c == 34) {                                  // the packed net input: 16 bytes per pixel, one piece per pixel
+        gx = xs + lane; base = reinterpret_cast<const char*>(p.x0); pxbytes = 16; q.rb = (size_t)W * 16;
+        q.isg = 0; q.rowb = 1024; q.dst = lds0 + CW_X0_OFF;
+      } else {                                               // dz6: 2 bytes per pixel, 8 pieces carry the 64 pixels
+        gx = lane < 8 ? xs + 8 * lane : W; base = reinterpret_cast<const char*>(p.dz6); pxbytes = 2; q.rb = (size_t)W * 2;
+        q.isg = 0; q.rowb = 1024; q.dst = lds0 + CW_Z6_OFF;
       }
-      // rows that exist nowhere: dA = w_out dz6 (gradient ring 3) for rows y + 1 (and y - 1, y on the first step), dz6 of row y as fp32,
-      // the packed net input of row y
-      if (wave == 13) {
-        for (int rr = first ? -1 : 1; rr <= 1; ++rr) {
-          const int row = y + rr;
-          for (int px = lane; px < WG_SW + 2; px += 64) {
-            const int gx = xs - 1 + px;
-            const bool ok = (unsigned)row < (unsigned)H && (unsigned)gx < (unsigned)W;
-            float dz = 0.f;
-            if (ok) dz = Elem<T>::to_f32(reinterpret_cast<const T*>(p.dz6)[(size_t)(b * H + row) * W + gx]);
-            if (rr == 0 || (!first && rr == 1 && false)) {}
-            char* o = smem + G_OFF + (3 * 4 + (row & 3)) * WG_GROW + px * PIXB;
+      q.colok = (unsigned)gx < (unsigned)W;
+      // (a strip's last dz6 piece may straddle the image edge: it then carries the next row's first values, which only ever meet zeros --
+      // the a3 row is zero there, and the ones of the bias row are switched off beyond the edge)
+      q.src = base + ((size_t)(b * H) * W + (q.colok ? gx : 0)) * pxbytes + part * 16;
+      return q;
+    };
+    const Piece q0 = make_piece(wave), q1 = make_piece(wave + 12), q2 = make_piece(wave + 24);
+    auto issue = [&](const Piece& q, int y) {
+      const int row = y + q.isg;
+      const bool ok = (unsigned)row < (unsigned)H && q.colok;
+      const char* src = ok ? q.src + (size_t)row * q.rb : reinterpret_cast<const char*>(p.zero16);
+      const unsigned dst = q.dst + (q.isg ? gslot(row) : aslot(row)) * q.rowb;
+      cw_dma_1k(src, (unsigned)sfl((int)dst));
+    };
+    auto dma = [&](int y) { issue(q0, y); issue(q1, y); issue(q2, y); };
+    // the first call of a unit also needs gradient rows y - 1 and y: the sixteen gradient pieces, twice (waves 0..7 take two of each)
+    auto dma_first = [&](int y) {
 #pragma unroll
-            for (int q4 = 0; q4 < 6; ++q4) {
-              const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(smem + LDS_END) + q4 * 4);
-              *reinterpret_cast<uint2*>(o + q4 * 8) = uint2{pack2<T>(wv[0] * dz, wv[1] * dz), pack2<T>(wv[2] * dz, wv[3] * dz)};
-            }
-          }
-        }
-        for (int px = lane; px < WG_SW; px += 64) {
-          const int gx = xs + px;
-          const bool ok = (unsigned)y < (unsigned)H && (unsigned)gx < (unsigned)W;
-          reinterpret_cast<float*>(smem + Z6_OFF + (y & 1) * 512)[px] = ok ? Elem<T>::to_f32(reinterpret_cast<const T*>(p.dz6)[(size_t)(b * H + y) * W + gx]) : 0.f;
-        }
-      }
-      if (wave == 12) {
-        for (int px = lane; px < WG_SW; px += 64) {
-          const int gx = xs + px;
-          const bool ok = (unsigned)y < (unsigned)H && (unsigned)gx < (unsigned)W;
-          float s3[3] = {0.f, 0.f, 0.f}, f3[3] = {0.f, 0.f, 0.f};
-          if (ok) {
-            const float* sp = p.small + (size_t)((b * h2 + (y >> 1)) * w2 + (gx >> 1)) * p.ld_small;
-            const float* fp = p.fine + (size_t)((b * H + y) * W + gx) * p.ld_fine;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { s3[c] = sp[c]; f3[c] = fp[c]; }
-          }
-          // [up(small) | fine | 1 (bias row) | 0], rounded to the storage type as the layer-wise path stores the packed net input
-          *reinterpret_cast<uint4*>(smem + X0_OFF + (y & 1) * 1024 + px * 16) =
-              uint4{pack2<T>(s3[0], s3[1]), pack2<T>(s3[2], f3[0]), pack2<T>(f3[1], f3[2]), ok ? ONE : 0u};
+      for (int e = 0; e < 3; ++e) {
+        const int c = wave + 12 * e;                          // 0..31 used
+        if (c < 32) {
+          const int tensor = (c >> 2) & 3, chunk = c & 3, row = y - 1 + (c >> 4);
+          const int piece = chunk * 64 + lane, px = (piece * 171) >> 9, part = piece - px * 3;
+          const int gx = xs - 1 + px;
+          const bool ok = (unsigned)row < (unsigned)H && (unsigned)gx < (unsigned)W;
+          const char* src = ok ? reinterpret_cast<const char*>(p.g[1 + tensor]) + ((size_t)((b * H + row) * W + gx) * 24) * 2 + part * 16
+                               : reinterpret_cast<const char*>(p.zero16);
+          cw_dma_1k(src, (unsigned)sfl((int)(lds0 + CW_G_OFF + (tensor * 5 + gslot(row)) * WG_GROW + chunk * 1024)));
         }
       }
     };
-    fetch(yb0, true);
+    dma_first(yb0);
+    dma(yb0);
+    dma(yb0 + 1);
     for (int y = yb0; y < yb1; ++y) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      cw_wait_vm<3>();                                        // the pieces of row y were requested two calls ago; the latest call's 3 may be in flight
       __syncthreads();
-      if (y + 1 < yb1) fetch(y + 1, false);
+      dma(y + 2);
       // ---- this row: 4 K-steps of 16 pixels
-      if (wave < 12) {
-        const int gt = layer == 0 ? 0 : layer == 1 ? 1 : layer == 2 ? 2 : 3;             // gradient ring: dc1, d a2, dc3, dA
-        const int grow = y - (dyi - 1);                                                   // tap row dyi pairs act row y with gradient row y - (dyi - 1)
-        const unsigned abase = lds0 + A_OFF + (layer * 2 + (y & 1)) * WG_AROW + tr_lane + kh * 8 * PIXB;
-        const unsigned gbase = lds0 + G_OFF + (gt * 4 + (grow & 3)) * WG_GROW + tr_lane + kh * 8 * PIXB;      // position 0 = pixel xs - 1
-        const bool g_ok = (unsigned)grow < (unsigned)H;
-        if (g_ok) {
+      const int grow = y - (dyi - 1);                                                   // tap row dyi pairs act row y with gradient row y - (dyi - 1)
+      const unsigned abase = lds0 + CW_A_OFF + (layer * 3 + aslot(y)) * WG_AROW + tr_lane + kh * 8 * PIXB;
+      const unsigned gbase = lds0 + CW_G_OFF + (layer * 5 + gslot(grow)) * WG_GROW + tr_lane + kh * 8 * PIXB;      // position 0 = pixel xs - 1
+      if ((unsigned)grow < (unsigned)H) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            // A: 8 pixels x0 + 8 kh .. of channel m
-            const uint2 a_lo = cw_tr(abase + k * 16 * PIXB), a_hi = cw_tr(abase + k * 16 * PIXB + 4 * PIXB);
-            uint4 af = {a_lo.x, a_lo.y, a_hi.x, a_hi.y};
-            if (layer == 2) af = relu16<T>(af);                                           // conv2d_3 read relu(a2); a2 is stored raw
-            if (ones_row && dyi == 1) af = uint4{ONE2, ONE2, ONE2, ONE2};               // channel 24 := 1: row 24 of the centre tap = bias gradient
-            // window of the gradient row: pixels (x0 + 8 kh) - 1 .. + 10 relative to the activation pixels (ring position + 1 = same pixel)
-            const uint2 w01 = cw_tr(gbase + k * 16 * PIXB), w23 = cw_tr(gbase + k * 16 * PIXB + 4 * PIXB), w45 = cw_tr(gbase + k * 16 * PIXB + 8 * PIXB);
-            // tap dx = 0 pairs act pixel q with gradient pixel q + 1, dx = 1 with q, dx = 2 with q - 1
-            const uint4 f_m1 = {w01.x, w01.y, w23.x, w23.y};                              // pixels q - 1 ..
-            const uint4 f_p1 = {w01.y, w23.x, w23.y, w45.x};                              // pixels q + 1 ..
-            const uint4 f_0 = {__builtin_amdgcn_alignbit(w01.y, w01.x, 16), __builtin_amdgcn_alignbit(w23.x, w01.y, 16),
-                               __builtin_amdgcn_alignbit(w23.y, w23.x, 16), __builtin_amdgcn_alignbit(w45.x, w23.y, 16)};
-            acc[0] = mma32<T>(af, f_p1, acc[0]);
-            acc[1] = mma32<T>(af, f_0, acc[1]);
-            acc[2] = mma32<T>(af, f_m1, acc[2]);
-          }
+        for (int k = 0; k < 4; ++k) {
+          // A: 8 pixels x0 + 8 kh .. of channel m
+          const uint2 a_lo = cw_tr(abase + k * 16 * PIXB), a_hi = cw_tr(abase + k * 16 * PIXB + 4 * PIXB);
+          uint4 af = {a_lo.x, a_lo.y, a_hi.x, a_hi.y};
+          if (layer == 2) af = relu16<T>(af);                                           // conv2d_3 read relu(a2); a2 is stored raw
+          if (ones_row && dyi == 1) af = uint4{ONE2, ONE2, ONE2, ONE2};               // channel 24 := 1: row 24 of the centre tap = bias gradient
+          // window of the gradient row: pixels q - 1 .. q + 10 for the activation pixels q = x0 + 8 kh .. (ring position + 1 = same pixel)
+          const uint2 w01 = cw_tr(gbase + k * 16 * PIXB), w23 = cw_tr(gbase + k * 16 * PIXB + 4 * PIXB), w45 = cw_tr(gbase + k * 16 * PIXB + 8 * PIXB);
+          // tap dx = 0 pairs act pixel q with gradient pixel q + 1, dx = 1 with q, dx = 2 with q - 1
+          const uint4 f_m1 = {w01.x, w01.y, w23.x, w23.y};
+          const uint4 f_p1 = {w01.y, w23.x, w23.y, w45.x};
+          const uint4 f_0 = {__builtin_amdgcn_alignbit(w01.y, w01.x, 16), __builtin_amdgcn_alignbit(w23.x, w01.y, 16),
+                             __builtin_amdgcn_alignbit(w23.y, w23.x, 16), __builtin_amdgcn_alignbit(w45.x, w23.y, 16)};
+          acc[0] = mma32<T>(af, f_p1, acc[0]);
+          acc[1] = mma32<T>(af, f_0, acc[1]);
+          acc[2] = mma32<T>(af, f_m1, acc[2]);
         }
-      } else if (wave == 12) {
-        // dW1[k][n] += x0[k] dz1[n] (row 6 of the result: db1)
-        const unsigned xbase = lds0 + X0_OFF + (y & 1) * 1024 + (unsigned)((t16 >> 2) * 16 + (t16 & 3) * 8) + kh * 8 * 16;
-        const unsigned zbase = lds0 + Z1_OFF + (y & 1) * WG_AROW + tr_lane + kh * 8 * PIXB;
+      }
+      if (wave == 0) {
+        // dW1[k][n] += x0[k] dz1[n] (row 6 of the result: db1, the ones channel of the packed net input)
+        const unsigned xbase = lds0 + CW_X0_OFF + aslot(y) * 1024 + (unsigned)((t16 >> 2) * 16 + (t16 & 3) * 8) + kh * 8 * 16;
+        const unsigned zbase = lds0 + CW_Z1_OFF + aslot(y) * WG_AROW + tr_lane + kh * 8 * PIXB;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           uint4 af = {0u, 0u, 0u, 0u};
@@ -650,61 +674,61 @@ __global__ __launch_bounds__(WG_WAVES * 64) void compose_stream_wgrad_kernel(con
             af = uint4{a_lo.x, a_lo.y, a_hi.x, a_hi.y};
           }
           const uint2 b_lo = cw_tr(zbase + k * 16 * PIXB), b_hi = cw_tr(zbase + k * 16 * PIXB + 4 * PIXB);
-          acc[0] = mma32<T>(af, uint4{b_lo.x, b_lo.y, b_hi.x, b_hi.y}, acc[0]);
+          acc[3] = mma32<T>(af, uint4{b_lo.x, b_lo.y, b_hi.x, b_hi.y}, acc[3]);
         }
-      } else {
-        // dW6[n] += a3[n] dz6 (row 24: db6): the B operand has ONE column
-        const unsigned abase = lds0 + A3_OFF + (y & 1) * WG_AROW + tr_lane + kh * 8 * PIXB;
-        const float* z6 = reinterpret_cast<const float*>(smem + Z6_OFF + (y & 1) * 512);
+      } else if (wave == 1) {
+        // dW6[n] += a3[n] dz6 (row 24: db6): the B operand has ONE column, 8 consecutive dz6 values per k-half
+        const unsigned a3base = lds0 + CW_A3_OFF + aslot(y) * WG_AROW + tr_lane + kh * 8 * PIXB;
+        const char* z6 = smem + CW_Z6_OFF + aslot(y) * 1024;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint2 a_lo = cw_tr(abase + k * 16 * PIXB), a_hi = cw_tr(abase + k * 16 * PIXB + 4 * PIXB);
+          const uint2 a_lo = cw_tr(a3base + k * 16 * PIXB), a_hi = cw_tr(a3base + k * 16 * PIXB + 4 * PIXB);
           uint4 af = {a_lo.x, a_lo.y, a_hi.x, a_hi.y};
-          if (ones_row) af = uint4{ONE2, ONE2, ONE2, ONE2};
-          uint4 bf = {0u, 0u, 0u, 0u};
-          if (m == 0) {
-            const float* z = z6 + k * 16 + kh * 8;
-            bf = uint4{pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]), pack2<T>(z[4], z[5]), pack2<T>(z[6], z[7])};
+          if (ones_row) {
+            const int px = xs + k * 16 + kh * 8;               // W is even: pixel pairs are inside or outside together
+            af = uint4{px < W ? ONE2 : 0u, px + 2 < W ? ONE2 : 0u, px + 4 < W ? ONE2 : 0u, px + 6 < W ? ONE2 : 0u};
           }
-          acc[0] = mma32<T>(af, bf, acc[0]);
+          uint4 bfr = {0u, 0u, 0u, 0u};
+          if (m == 0) bfr = *reinterpret_cast<const uint4*>(z6 + (k * 16 + kh * 8) * 2);
+          acc[3] = mma32<T>(af, bfr, acc[3]);
         }
       }
     }
-    __syncthreads();                                          // the next unit's first fetch overwrites the rows
+    cw_wait_vm<0>();                                          // the rows requested past the band
+    __syncthreads();                                          // the next unit's prologue overwrites the rows
   }
 
   // ---- flush: one atomic per gradient element per workgroup
   if (u1 > u0) {
-    if (wave < 12) {
-      float* dw = p.dw_res[layer];
+    float* dw = p.dw_res[layer];
 #pragma unroll
-      for (int dxi = 0; dxi < 3; ++dxi) {
-        const int tap = dyi * 3 + dxi;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i >> 2) * 8 + kh * 4 + (i & 3), col = m;
-          if (col < 24) {
-            if (row < 24) atomicAdd(dw + (tap * 24 + row) * 24 + col, acc[dxi][i]);
-            else if (row == 24 && tap == 4) atomicAdd(p.db_res[layer] + col, acc[dxi][i]);
-          }
-        }
-      }
-    } else if (wave == 12) {
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int tap = dyi * 3 + dxi;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i >> 2) * 8 + kh * 4 + (i & 3), col = m;
         if (col < 24) {
-          if (row < 6) atomicAdd(p.dw_in + row * 24 + col, acc[0][i]);
-          else if (row == 6) atomicAdd(p.db_in + col, acc[0][i]);
+          if (row < 24) atomicAdd(dw + (tap * 24 + row) * 24 + col, acc[dxi][i]);
+          else if (row == 24 && tap == 4) atomicAdd(p.db_res[layer] + col, acc[dxi][i]);
         }
       }
-    } else {
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i >> 2) * 8 + kh * 4 + (i & 3), col = m;
+        if (col < 24) {
+          if (row < 6) atomicAdd(p.dw_in + row * 24 + col, acc[3][i]);
+          else if (row == 6) atomicAdd(p.db_in + col, acc[3][i]);
+        }
+      }
+    } else if (wave == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i >> 2) * 8 + kh * 4 + (i & 3);
         if (m == 0) {
-          if (row < 24) atomicAdd(p.dw_out + row, acc[0][i]);
-          else if (row == 24) atomicAdd(p.db_out, acc[0][i]);
+          if (row < 24) atomicAdd(p.dw_out + row, acc[3][i]);
+          else if (row == 24) atomicAdd(p.db_out, acc[3][i]);
         }
       }
     }
@@ -717,17 +741,16 @@ static __device__ uint4 dd_cw_zero_page = {0u, 0u, 0u, 0u};
 
 int dd_compose_stream_wgrad_launch(const dd_compose_bwd_args* a, void* scratch, hipStream_t s) {
   CwP p;
-  p.small = a->small; p.fine = a->fine; p.w_out = a->w_out;
   for (int i = 0; i < 5; ++i) p.act[i] = a->act[i];
   const long npix = (long)a->N * a->H * a->W;
-  for (int i = 0; i < 4; ++i) p.g[i] = reinterpret_cast<char*>(scratch) + (size_t)i * npix * 48;
-  p.dz6 = reinterpret_cast<char*>(scratch) + (size_t)4 * npix * 48;
+  for (int i = 0; i < 5; ++i) p.g[i] = reinterpret_cast<char*>(scratch) + (size_t)i * npix * 48;
+  p.x0 = reinterpret_cast<char*>(scratch) + (size_t)5 * npix * 48;
+  p.dz6 = reinterpret_cast<char*>(scratch) + (size_t)npix * (5 * 48 + 16);
   void* zp = nullptr;
   if (hipGetSymbolAddress(&zp, HIP_SYMBOL(dd_cw_zero_page)) != hipSuccess) { dd_set_error("dd_compose_net_bwd: no zero page"); return DD_ERR_LAUNCH; }
   p.zero16 = zp;
   p.dw_in = a->dw_in; p.db_in = a->db_in; p.dw_out = a->dw_out; p.db_out = a->db_out;
   for (int l = 0; l < 4; ++l) { p.dw_res[l] = a->dw_res[l]; p.db_res[l] = a->db_res[l]; }
-  p.ld_small = a->ld_small; p.ld_fine = a->ld_fine;
   p.N = a->N; p.H = a->H; p.W = a->W;
   p.strips = (a->W + WG_SW - 1) / WG_SW;
   const int cus = dd_device_cus();
@@ -745,7 +768,7 @@ int dd_compose_stream_wgrad_launch(const dd_compose_bwd_args* a, void* scratch, 
   p.BH = bestBH; p.nb = (a->H + bestBH - 1) / bestBH;
   p.units = a->N * p.strips * p.nb;
   const int grid = p.units < cus ? p.units : cus;
-  constexpr int LDS = 16 * WG_GROW + 8 * WG_AROW + 4 * WG_AROW + 2 * 1024 + 2 * 512 + 128;
+  constexpr int LDS = CW_LDS;
   if (a->dtype == DD_BF16) {
     dd_allow_max_lds(reinterpret_cast<const void*>(compose_stream_wgrad_kernel<bf16_t>));
     hipLaunchKernelGGL(compose_stream_wgrad_kernel<bf16_t>, dim3(grid), dim3(WG_WAVES * 64), LDS, s, p);

@@ -298,8 +298,13 @@ typedef struct {
   float* d_fine; int ld_dfine;
   float* dw_in; float* db_in; float* dw_res[4]; float* db_res[4]; float* dw_out; float* db_out;
   int N, H, W, dtype;
+  void* scratch; long scratch_bytes;       /* optional: >= dd_compose_bwd_scratch_bytes(N, H, W) bytes, 16-byte aligned (see below) */
 } dd_compose_bwd_args;
 int dd_compose_net_bwd(const dd_compose_bwd_args* a, dd_stream stream);
+/* With `scratch` the backward runs as two row-streaming launches (csrc/dd_compose_stream_bwd.hip): the data-gradient chain, which parks the
+ * four 24-channel gradient tensors and dz6 in scratch, then the weight gradients, which read every stored activation and parked gradient once.
+ * Needs act[] rows of exactly 24 channels (ld_act == 24).  Without scratch (NULL): the 16x16-tile kernel of csrc/dd_compose.hip. */
+long dd_compose_bwd_scratch_bytes(int N, int H, int W);
 
 /* ---- inverse standardization (Architecture.py:48-55, Utilities.py:6-7), in place capable */
 int dd_invert_std_fwd(const float* x, float* y, long n, int use_log1p, float mean, float std, dd_stream stream);

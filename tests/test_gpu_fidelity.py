@@ -32,10 +32,10 @@ def _task(arch, seed=0):
     return feats, labels
 
 
-def _train(dtype):
+def _train(dtype, aj=None):
     from deepdenoiser_amd.architecture import Architecture
     from deepdenoiser_amd.training import Trainer
-    aj, tj = configs.cfg2_unet_kpcn(filters=(32, 48, 64), convs=2), configs.bench_training()
+    aj, tj = aj or configs.cfg2_unet_kpcn(filters=(32, 48, 64), convs=2), configs.bench_training()
     arch = Architecture(aj, device="cuda", dtype=dtype, seed=2)
     trainer = Trainer(arch, tj, B, T, T, use_graph=True)
     feats, labels = _task(arch)
@@ -58,4 +58,21 @@ def test_half_precision_training_ends_where_f32_training_ends():
     for d in ("bf16", "f16"):
         assert abs(head[d] - head["f32"]) <= 0.02 * head["f32"]
         # same destination within a few percent of the f32 run's final loss (training noise of a 200-step run included)
+        assert abs(tail[d] - tail["f32"]) <= 0.08 * tail["f32"], (d, tail[d], tail["f32"])
+
+
+def test_tiramisu_half_precision_training_ends_where_f32_training_ends():
+    """BASELINE config 3 (Tiramisu.py:26-111 + MultiScalePrediction): the same 200-step question for the dense-block backbone -- the layer-wise
+    kernel-prediction head of this config stores its 25 logits in the storage type, and its single-step half-precision gradients are gated only
+    loosely (tests/test_gpu_round3.py); what a user needs is that training still goes where f32 training goes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    aj = configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4)
+    runs = {d: _train(d, aj) for d in ("f32", "bf16", "f16")}
+    tail = {d: sum(v[-20:]) / 20 for d, v in runs.items()}
+    head = {d: v[0] for d, v in runs.items()}
+    print("Tiramisu: loss at step 1 / mean of the last 20 of %d steps: " % STEPS + ", ".join("%s %.4f / %.4f" % (d, head[d], tail[d]) for d in runs))
+    assert tail["f32"] < 0.5 * head["f32"], "the task is not being learned"
+    for d in ("bf16", "f16"):
+        assert abs(head[d] - head["f32"]) <= 0.02 * head["f32"]
         assert abs(tail[d] - tail["f32"]) <= 0.08 * tail["f32"], (d, tail[d], tail["f32"])
