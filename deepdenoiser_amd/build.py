@@ -33,6 +33,7 @@ NO_SCRATCH = {
     "dd_conv_pw.hip": ("conv_pw_kernel", "wgrad_pw_kernel"),
     "dd_conv_pair.hip": ("conv_pair_kernel",),
     "dd_compose_stream.hip": ("compose_stream_fwd_kernel",),
+    "dd_compose_stream_bwd.hip": ("compose_stream_wgrad_kernel",),
 }
 
 

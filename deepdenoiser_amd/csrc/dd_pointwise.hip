@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
   const int y = y0 + ly, x = x0 + lx;
   const bool live = y < H && x < W;
   const long pix = ((long)b * H + (live ? y : 0)) * W + (live ? x : 0);
-  T* mine = s_out + threadIdx.x * c_pad;
+  // a pixel's row is c_pad elements + 4 bytes: with rows of exactly 64 bytes (32 bf16 channels) the 64 lanes of a wave, each storing into its own
+  // row, hit 4 bank groups (16-way conflicts on every 2-byte store); 68 bytes = 17 banks spreads them over all 64
+  const int rstride = c_pad + 4 / (int)sizeof(T);
+  T* mine = s_out + threadIdx.x * rstride;
   for (int c = 0; c < c_pad; ++c) mine[c] = Elem<T>::from_f32(0.f);
   // The haloed source tile of the NEXT pass is requested (into registers: 2 pixels x 3 channels per thread) while this pass is standardised and
   // its variance taken from LDS: one exposed memory round trip per tile instead of one per pass (8 passes: 249 -> see DESIGN 3.3).
@@ -563,8 +566,10 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
   for (int v = threadIdx.x; v < 256 * vpp; v += 256) {
     const int p = v / vpp, k = v - p * vpp;
     const int py = p >> 4, px = p & 15;
-    if (y0 + py < H && x0 + px < W)
-      *reinterpret_cast<uint4*>(img_out + ((long)(y0 + py) * W + x0 + px) * ld + k * N) = *reinterpret_cast<const uint4*>(s_out + p * c_pad + k * N);
+    if (y0 + py < H && x0 + px < W) {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(s_out + p * rstride + k * N);      // (4-byte aligned rows: four dword reads)
+      *reinterpret_cast<uint4*>(img_out + ((long)(y0 + py) * W + x0 + px) * ld + k * N) = uint4{w[0], w[1], w[2], w[3]};
+    }
   }
 }
 extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
@@ -573,7 +578,7 @@ extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, i
   DD_REQUIRE(dd_dtype_ok(dtype), "dd_assemble_input: bad dtype %d", dtype);
   const int per16 = dtype == DD_F32 ? 4 : 8, esz = dtype == DD_F32 ? 4 : 2;
   DD_REQUIRE(c_pad % per16 == 0 && ld % per16 == 0 && ((uintptr_t)dst % 16) == 0, "dd_assemble_input: c_pad=%d and ld=%d must be multiples of %d", c_pad, ld, per16);
-  const size_t lds = (size_t)256 * c_pad * esz;
+  const size_t lds = (size_t)256 * (c_pad * esz + 4);
   DD_REQUIRE(lds <= 96 * 1024, "dd_assemble_input: %d input channels do not fit the LDS tile", c_pad);
   const int tiles_x = dd_ceil_div(W, 16), tiles_y = dd_ceil_div(H, 16);
   const unsigned grid = (unsigned)((long)n_tuples * B * tiles_x * tiles_y);

@@ -86,3 +86,19 @@ def test_build_refuses_scratch_in_kernels_with_inplace_asm_accumulators():
     with pytest.raises(RuntimeError, match="no resource-usage remark"):
         build._check_no_scratch("dd_conv_bwd.hip", ("conv_bwd_kernel",), "nothing here")
     assert set(build.NO_SCRATCH) <= set(build.SOURCES)
+
+
+def test_compose_stream_plan_covers_every_pixel_once(lib):
+    """dd_compose_stream_plan (host only): the strip / band geometry of the row-streaming compose kernels.  Strips and bands must tile the image,
+    frames must hold a strip plus its 4-column halo and fit the 128-pixel step, bands must be a whole number of steps."""
+    import ctypes
+    for N, H, W in [(128, 128, 128), (128, 64, 64), (53, 128, 128), (8, 256, 256), (3, 24, 40), (1, 16, 16), (2, 64, 64), (1, 20, 12), (209, 128, 128),
+                    (1, 2, 2), (4, 258, 130), (1, 1080, 1920)]:
+        o = (ctypes.c_int * 8)()
+        assert lib.dd_compose_stream_plan(N, H, W, 256, o) == 0
+        FW, R, TPR, strips, SO, BH, nb, VB = list(o)
+        assert FW % 32 == 0 and 32 <= FW <= 128 and TPR == FW // 32 and R == {32: 4, 64: 2, 96: 1, 128: 1}[FW]
+        assert strips * SO >= W and SO % 2 == 0 and (strips == 1 or FW >= SO + 8) and (strips > 1 or FW >= W)
+        assert BH % 4 == 0 and nb * BH >= H and (nb - 1) * BH < H and VB == BH + 8 and VB % R == 0
+    assert lib.dd_compose_stream_plan(0, 8, 8, 256, (ctypes.c_int * 8)()) == -1
+    assert lib.dd_compose_bwd_scratch_bytes(2, 16, 32) == 2 * 16 * 32 * 272

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("bench.json", "kernel_stats.txt", "inference.json", "host_inputs.txt", "pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt",
              "pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt", "two_ranks_one_gpu.txt", "one_rank_rccl.txt", "inference_kernel_stats.txt", "cfg3_heavy_kernel_stats.txt",
-             "cfg3_light_kernel_stats.txt"):
+             "cfg3_light_kernel_stats.txt", "cfg3_light_pmc_FETCH_SIZE.txt", "cfg3_light_pmc_WRITE_SIZE.txt", "cfg3_light_pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt",
+             "cfg3_heavy_pmc_FETCH_SIZE.txt", "cfg3_heavy_pmc_WRITE_SIZE.txt", "cfg3_heavy_pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt", "conv_launches.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         out = os.path.join(dst, "%s_%s" % (tag, name.replace("pmc_SQ_VALU_MFMA_BUSY_CYCLES", "pmc_MFMA_BUSY")))

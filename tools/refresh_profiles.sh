@@ -8,7 +8,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
-timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
+timeout 600 python bench.py --dump-launches $out/conv_launches.json > $out/bench.json 2> $out/bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-extras --host-inputs 2>/dev/null | tail -1 > $out/host_inputs.txt
 timeout 300 python bench.py --mode inference --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/inference.json
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- python bench.py --no-cpu-baseline --no-extras > $out/prof.log 2>&1
@@ -25,7 +25,16 @@ grep "^cfg-3" $out/prof_cfg3l.log >> $out/cfg3_light_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $c -d $out/pmc_$n -o pmc --output-format csv -- python bench.py --no-cpu-baseline --no-extras --no-graph --steps 2 --warmup 1 > $out/pmc_$n.log 2>&1
-  python tools/pmc_family.py $out/pmc_$n conv_igemm conv_rw conv_ks conv_pw wgrad_pw wgrad_dma conv_bwd convt_fwd convt_bwd compose_fwd compose_bwd head_fwd head_bwd maxpool > $out/pmc_$n.txt 2>&1
+  python tools/pmc_family.py $out/pmc_$n conv_igemm conv_rw conv_ks conv_pw wgrad_pw wgrad_dma conv_bwd convt_fwd convt_bwd compose_stream_fwd compose_stream_bwd compose_stream_wgrad head_fwd head_bwd maxpool assemble_input > $out/pmc_$n.txt 2>&1
+done
+# BASELINE config 3 from the counters: HBM traffic and matrix-pipe busy of both Tiramisu configurations, per kernel family
+for cfg in light heavy; do
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"; do
+    n=$(echo $c | cut -d' ' -f1)
+    timeout 600 rocprofv3 --pmc $c -d $out/pmc3_${cfg}_$n -o pmc --output-format csv -- python tools/cfg3_step.py $cfg 8 2 > $out/pmc3_${cfg}_$n.log 2>&1
+    python tools/pmc_family.py $out/pmc3_${cfg}_$n conv_ks conv_pw wgrad_pw wgrad_dma conv_igemm conv_rw conv_bwd compose_stream kpcn masked_add colsum maxpool > $out/cfg3_${cfg}_pmc_$n.txt 2>&1
+    rm -rf $out/pmc3_${cfg}_$n
+  done
 done
 # the multi-process path of the bench on ONE device (two ranks, gloo transport; RCCL needs >= 2 GPUs): same code above the transport
 HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_DEVICE=0 DD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 3 --batch 32 > $out/two_ranks_one_gpu.txt 2> $out/two_ranks_one_gpu.err
