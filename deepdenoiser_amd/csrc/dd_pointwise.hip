@@ -220,6 +220,19 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restri
   if (N == 8) *reinterpret_cast<uint2*>(idx + opix * C + c) = make_uint2(packed[0], packed[N / 4 - 1]);
   else *reinterpret_cast<uint32_t*>(idx + opix * C + c) = packed[0];
 }
+// Stride-2 specialisation of the BACKWARD (POOL = 3: the U-Net's pooling, POOL = 2: Tiramisu's).  The generic kernel above loops over a RUN-TIME
+// window: hipcc cannot unroll it, so a thread's loads are issued one after the other, and its index arithmetic is three 64-bit divisions per
+// thread -- it ran at 2.4 - 2.9 TB/s of traffic.  Here the window is a template constant (every load of a thread is in flight at once,
+// out-of-image windows read a clamped address and count as "no gradient"), the index arithmetic is 32-bit, and a thread owns a 2 x 2 block of input
+// pixels: with stride 2 the four pixels share their (at most four) windows, so a block costs 4 (index, gradient) loads instead of the 9 the
+// per-pixel kernel issues for the same four pixels.  Measured (tools/maxpool_bench.py, bf16, accumulate): 128 x 128 x 128 x 64 217 -> 136 us
+// (4.7 TB/s), 128 x 64 x 64 x 96 61 -> 47 us.  The same treatment of the FORWARD (nine loads in flight, 32-bit indices) measured SLOWER than the
+// generic kernel (84 -> 95 us: it is bound by the 2.25x re-reads through L2, not by load latency) and is not kept.
+// (the 32-bit offsets of the specialisations: every tensor involved must have fewer than 2^31 elements)
+static bool pool_s2_ok(int pool, int stride, int B, int H, int W, int ld_big) {
+  static const bool generic = getenv("DD_MAXPOOL_GENERIC") && getenv("DD_MAXPOOL_GENERIC")[0] == '1';      // (A/B switch)
+  return !generic && stride == 2 && (pool == 2 || pool == 3) && (double)B * H * W * ld_big < 2147483648.0;
+}
 extern "C" int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
                               int pool, int stride, int relu_mask, int dtype, dd_stream stream) {
   const int per16 = dtype == DD_F32 ? 4 : 8;
@@ -285,6 +298,86 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uin
   }
   vstore<T>(dst, g);
 }
+// One thread = a 2 x 2 block of input pixels (rows 2k - pby + {0, 1}, columns 2j - pbx + {0, 1}) x 16 bytes of channels.  In padded coordinates
+// the even row 2k lies in window k (offset 0) and, for POOL = 3, in window k - 1 (offset 2); the odd row only in window k (offset 1).
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void maxpool_bwd_s2_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int lddx,
+                                                             const T* __restrict__ mask, int ldmask, int C, unsigned total, int H, int W, int OH, int OW,
+                                                             int KB, int JB, int pby, int pbx, int accumulate) {
+  constexpr int N = Elem<T>::PER16, NWIN = POOL == 3 ? 2 : 1;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned cg = (unsigned)C / N;
+  unsigned r = i / cg;
+  const int c = (int)(i - r * cg) * N;
+  const int j = (int)(r % (unsigned)JB); r /= (unsigned)JB;
+  const int k = (int)(r % (unsigned)KB);
+  const int b = (int)(r / (unsigned)KB);
+  float g[2][2][N];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < N; ++e) g[q >> 1][q & 1][e] = 0.f;
+  const size_t ob = (size_t)b * OH * OW;
+  uint32_t am[NWIN * NWIN][N / 4];
+  float v[NWIN * NWIN][N];
+#pragma unroll
+  for (int wy = 0; wy < NWIN; ++wy)
+#pragma unroll
+    for (int wx = 0; wx < NWIN; ++wx) {
+      const int oy = k - wy, ox = j - wx, w = wy * NWIN + wx;
+      const bool ok = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+      const size_t opix = ob + (ok ? (unsigned)(oy * OW + ox) : 0u);
+      if (N == 8) { const uint2 t = *reinterpret_cast<const uint2*>(idx + opix * C + c); am[w][0] = t.x; am[w][N / 4 - 1] = t.y; }
+      else am[w][0] = *reinterpret_cast<const uint32_t*>(idx + opix * C + c);
+      vload<T>(dy + opix * lddy + c, v[w]);
+      if (!ok) {
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) am[w][q] = 0xFFFFFFFFu;      // 255: "no gradient"
+      }
+    }
+  const int y0 = 2 * k - pby, x0 = 2 * j - pbx;
+  float old[2][2][N], mk[2][2][N];
+#pragma unroll
+  for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+      const bool ok = (unsigned)(y0 + ay) < (unsigned)H && (unsigned)(x0 + ax) < (unsigned)W;
+      const size_t pix = (size_t)b * H * W + (ok ? (unsigned)((y0 + ay) * W + x0 + ax) : 0u);
+      if (accumulate) vload<T>(dx + pix * lddx + c, old[ay][ax]);
+      if (mask) vload<T>(mask + pix * ldmask + c, mk[ay][ax]);
+    }
+#pragma unroll
+  for (int wy = 0; wy < NWIN; ++wy)
+#pragma unroll
+    for (int wx = 0; wx < NWIN; ++wx)
+#pragma unroll
+      for (int ay = 0; ay < (wy ? 1 : 2); ++ay)
+#pragma unroll
+        for (int ax = 0; ax < (wx ? 1 : 2); ++ax) {
+          const uint32_t kk = (uint32_t)((wy ? 2 : ay) * POOL + (wx ? 2 : ax));
+          const int w = wy * NWIN + wx;
+#pragma unroll
+          for (int e = 0; e < N; ++e)
+            if (((am[w][e >> 2] >> (8 * (e & 3))) & 255u) == kk) g[ay][ax][e] += v[w][e];
+        }
+#pragma unroll
+  for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+      if (!((unsigned)(y0 + ay) < (unsigned)H && (unsigned)(x0 + ax) < (unsigned)W)) continue;
+      const size_t pix = (size_t)b * H * W + (unsigned)((y0 + ay) * W + x0 + ax);
+      if (mask) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[ay][ax][e] = mk[ay][ax][e] > 0.f ? g[ay][ax][e] : 0.f;
+      }
+      if (accumulate) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[ay][ax][e] += old[ay][ax][e];
+      }
+      vstore<T>(dx + pix * lddx + c, g[ay][ax]);
+    }
+}
 extern "C" int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, const void* mask, int ldmask,
                               int C, int B, int H, int W, int pool, int stride, int accumulate, int dtype, dd_stream stream) {
   const int per16 = dtype == DD_F32 ? 4 : 8;
@@ -292,6 +385,14 @@ extern "C" int dd_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void
   DD_REQUIRE(dy && idx && dx && C % per16 == 0 && lddy % per16 == 0 && lddx % per16 == 0, "dd_maxpool_bwd: C, ld must be multiples of %d", per16);
   int OH, OW, pby, pbx;
   same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);
+  if (pool_s2_ok(pool, stride, B, H, W, lddx > C ? lddx : C)) {
+    const int KB = (H + pby + 1) / 2, JB = (W + pbx + 1) / 2;      // blocks of two padded rows / columns that hold an image pixel
+    const long nt = (long)B * KB * JB * (C / per16);
+    if (pool == 3) { DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_s2_kernel<T, 3>), dim3(grid_for(nt)), dim3(256), 0, S(stream), (const T*)dy, lddy, idx, (T*)dx, lddx, (const T*)mask, ldmask, C, (unsigned)nt, H, W, OH, OW, KB, JB, pby, pbx, accumulate)); }
+    else { DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_s2_kernel<T, 2>), dim3(grid_for(nt)), dim3(256), 0, S(stream), (const T*)dy, lddy, idx, (T*)dx, lddx, (const T*)mask, ldmask, C, (unsigned)nt, H, W, OH, OW, KB, JB, pby, pbx, accumulate)); }
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+  }
   const long total = (long)B * H * W * (C / per16);
   DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, S(stream), (const T*)dy, lddy, idx, (T*)dx, lddx, (const T*)mask, ldmask, C, B, H, W, OH, OW, pool, stride, pby, pbx, accumulate));
   DD_LAUNCH_CHECK();
@@ -448,17 +549,30 @@ extern "C" int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n
 // ------------------------------------------------------------------------------------------------ fused input assembly
 // dd_prepare_feature (one launch per render pass, fp32 staging planes) + dd_gather_input (one more pass over them) as ONE launch: a workgroup
 // owns a 16x16 tile of one (tuple, tile) image and walks the tuple's entry table -- per feature entry the 18x18 haloed source tile is staged
-// and standardised in LDS, the local variance taken from it, and the entry's channels written into an LDS image of the network-input tile,
-// which finally leaves as coalesced 16-byte vectors.  HBM sees the raw passes once (12 B per pixel and pass) and the network input once
-// (c_pad storage elements per pixel); the staging planes (16 B written + 16 B read per pixel and pass) are gone, except the standardised
-// source of the passes the kernel-prediction head filters (std_out != NULL), which it needs anyway.
+// and standardised in LDS, the local variance taken from it, and the entry's channels written straight into the network input.
+// HBM sees the raw passes once (12 B per pixel and pass) and the network input once (c_pad storage elements per pixel); the staging planes
+// (16 B written + 16 B read per pixel and pass) are gone, except the standardised source of the passes the kernel-prediction head filters
+// (std_out != NULL), which it needs anyway.
+// Round 4 (SQ counters: the kernel was VALU-bound, 3 300 vector instructions per wave and tile of eight passes, not memory-bound):
+//   * a pass's 4 channels enter the LDS image of the network-input tile as two dword stores (were four 2-byte stores), and only the padding
+//     channels are zeroed.  (Writing them straight to HBM instead, one 8-byte store per pixel and pass, measured SLOWER: 224 -> 247 us, the
+//     partial lines cost more than the LDS image and its coalesced copy-out);
+//   * the three fp32 divisions per channel of the variance (sum / count twice, var / max(mean^2, eps)) are multiplications by 1 / count and
+//     one v_rcp_f32 (<= 1 ulp; the relative variance is a network INPUT, the f32 parity gates hold: tests/test_gpu_ops.py);
+//   * sign(v) * log1p(|v|) instead of two log1p calls selected by sign.
+// (4-byte aligned destination: dword stores)
+template <typename T> __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void st4<float>(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) { uint32_t* q = reinterpret_cast<uint32_t*>(p); q[0] = pack2<bf16_t>(a, b); q[1] = pack2<bf16_t>(c, d); }
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, float a, float b, float c, float d) { uint32_t* q = reinterpret_cast<uint32_t*>(p); q[0] = pack2<f16_t>(a, b); q[1] = pack2<f16_t>(c, d); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_entry* __restrict__ table, int n_entries, T* __restrict__ dst, int ld, int c_pad,
                                                              int B, int H, int W, int tiles_x, int tiles_y) {
   constexpr int TP = 16, HP = TP + 2;
   __shared__ float s_std[3][HP][HP + 1];
   __shared__ float s_var[3][HP][HP + 1];
-  extern __shared__ __attribute__((aligned(16))) char s_out_raw[];      // [256 pixels][c_pad] of T
+  extern __shared__ __attribute__((aligned(16))) char s_out_raw[];      // [256 pixels][c_pad elements + 4 bytes] of T
   T* s_out = reinterpret_cast<T*>(s_out_raw);
   int bid = blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
@@ -470,12 +584,20 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
   const bool live = y < H && x < W;
   const long pix = ((long)b * H + (live ? y : 0)) * W + (live ? x : 0);
   // a pixel's row is c_pad elements + 4 bytes: with rows of exactly 64 bytes (32 bf16 channels) the 64 lanes of a wave, each storing into its own
-  // row, hit 4 bank groups (16-way conflicts on every 2-byte store); 68 bytes = 17 banks spreads them over all 64
+  // row, hit 4 bank groups; 68 bytes = 17 banks spreads them over all 64
   const int rstride = c_pad + 4 / (int)sizeof(T);
   T* mine = s_out + threadIdx.x * rstride;
-  for (int c = 0; c < c_pad; ++c) mine[c] = Elem<T>::from_f32(0.f);
   // The haloed source tile of the NEXT pass is requested (into registers: 2 pixels x 3 channels per thread) while this pass is standardised and
   // its variance taken from LDS: one exposed memory round trip per tile instead of one per pass (8 passes: 249 -> see DESIGN 3.3).
+  // The two haloed pixels a thread fetches are the same for every pass: their (mirrored) pixel offsets are computed once.
+  int hoff[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int k = threadIdx.x + it * 256;
+    const int py = k / HP, px = k - py * HP;
+    const int gy = sym_index(min(y0 - 1 + min(py, HP - 1), H), H), gx = sym_index(min(x0 - 1 + px, W), W);
+    hoff[it] = gy * W + gx;
+  }
   float raw[2][3];
   auto is_pass = [&](int e) { return e < n_entries && table[t * n_entries + e].nch > 0 && table[t * n_entries + e].kind == 0; };
   auto request = [&](int e) {
@@ -484,20 +606,22 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
     const float* img = en.src + (long)b * H * W * cs;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int k = threadIdx.x + it * 256;
-      const int py = k / HP, px = k - py * HP;
-      const int gy = sym_index(min(y0 - 1 + min(py, HP - 1), H), H), gx = sym_index(min(x0 - 1 + px, W), W);
-      const float* sp = img + ((long)gy * W + gx) * cs;
+      const float* sp = img + (long)hoff[it] * cs;
+#ifdef AI_EXP_NO_LOAD
+      raw[it][0] = raw[it][1] = raw[it][2] = (float)hoff[it]; (void)sp;
+#else
       if (cs == 3) { raw[it][0] = sp[0]; raw[it][1] = sp[1]; raw[it][2] = sp[2]; }
       else { raw[it][0] = sp[0]; raw[it][1] = 0.f; raw[it][2] = 0.f; }
+#endif
     }
   };
-  int e_next = 0;
+  int e_next = 0, used = 0;
   while (e_next < n_entries && !is_pass(e_next)) ++e_next;
   if (e_next < n_entries) request(e_next);
   for (int e = 0; e < n_entries; ++e) {
     const dd_assemble_entry en = table[t * n_entries + e];       // block-uniform
     if (en.nch <= 0) continue;
+    used = max(used, en.dst_ch + en.nch);
     if (en.kind == 1) {                                           // a vector broadcast over the tile (the tuple's embedding row)
       for (int c = 0; c < en.nch; ++c) mine[en.dst_ch + c] = Elem<T>::from_f32(en.src[c]);
       continue;
@@ -515,11 +639,18 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
       const int k = threadIdx.x + it * 256;
       if (k < HP * HP) {
         const int py = k / HP, px = k - py * HP;
-        for (int c = 0; c < cs; ++c) {
-          const float v = raw[it][c];
-          const float sv = standardize(v, fp);
-          s_std[c][py][px] = sv;
-          s_var[c][py][px] = fp.variance_before ? v : sv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (c < cs) {
+            const float v = raw[it][c];
+#ifdef AI_EXP_NO_LOG
+            const float sv = (v - fp.mean) * fp.inv_std;
+#else
+            const float sv = ((fp.use_log1p ? copysignf(log1pf(fabsf(v)), v) : v) - fp.mean) * fp.inv_std;
+#endif
+            s_std[c][py][px] = sv;
+            s_var[c][py][px] = fp.variance_before ? v : sv;
+          }
         }
       }
     }
@@ -531,33 +662,59 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
     rec[0] = s_std[0][ly + 1][lx + 1];
     rec[1] = cs == 3 ? s_std[1][ly + 1][lx + 1] : rec[0];
     rec[2] = cs == 3 ? s_std[2][ly + 1][lx + 1] : rec[0];
+    rec[3] = rec[4] = rec[5] = 0.f;
     int nv = 0;
     if (fp.use_variance) {
+      const float inv_cnt = fp.mode_neighbor ? 0.2f : (1.f / 9.f);
       float var_acc = 0.f;
-      for (int c = 0; c < cs; ++c) {
-        float sum = 0.f, sumsq = 0.f;
-        int cnt = 0;
 #pragma unroll
-        for (int a = -1; a <= 1; ++a)
+      for (int c = 0; c < 3; ++c) {
+        if (c < cs) {
+          float sum = 0.f, sumsq = 0.f;
 #pragma unroll
-          for (int bb = -1; bb <= 1; ++bb) {
-            if (fp.mode_neighbor && a != 0 && bb != 0) continue;
-            const float v = s_var[c][ly + 1 + a][lx + 1 + bb];
-            sum += v; sumsq += v * v; ++cnt;
-          }
-        const float mean = sum / cnt, meansq = sumsq / cnt;
-        float var = meansq - mean * mean;
-        if (fp.relative) var = var / fmaxf(mean * mean, fp.epsilon);
-        if (fp.compress) var_acc += var; else rec[3 + c] = var;
+          for (int a = -1; a <= 1; ++a)
+#pragma unroll
+            for (int bb = -1; bb <= 1; ++bb) {
+              if (a != 0 && bb != 0 && fp.mode_neighbor) continue;
+              const float v = s_var[c][ly + 1 + a][lx + 1 + bb];
+              sum += v; sumsq += v * v;
+            }
+          const float mean = sum * inv_cnt, meansq = sumsq * inv_cnt;
+          float var = meansq - mean * mean;
+          if (fp.relative) var = var * __builtin_amdgcn_rcpf(fmaxf(mean * mean, fp.epsilon));
+          var_acc += var;
+          rec[3 + c] = var;
+        }
       }
-      if (fp.compress) { rec[3] = var_acc / cs; nv = 1; } else nv = cs;
+      if (fp.compress) { rec[3] = var_acc * (cs == 3 ? (1.f / 3.f) : 1.f); nv = 1; } else nv = cs;
     }
-    for (int c = 0; c < 3 + nv && c < en.nch; ++c) mine[en.dst_ch + c] = Elem<T>::from_f32(rec[c]);
-    if (en.std_out && live) {
-      float* so = en.std_out + pix * en.ld_std;
-      for (int c = 0; c < 3 + nv && c < en.ld_std; ++c) so[c] = rec[c];
+    const int n = min(3 + nv, en.nch);
+    {
+      T* o = mine + en.dst_ch;
+      if (n == 4 && (en.dst_ch & 1) == 0) st4<T>(o, rec[0], rec[1], rec[2], rec[3]);      // (rows start 4-byte aligned)
+      else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          if (c < n) o[c] = Elem<T>::from_f32(rec[c]);
+      }
+    }
+    if (live) {
+#ifdef AI_EXP_NO_STDOUT
+      if (en.std_out && rec[0] == 123.456f) {
+#else
+      if (en.std_out) {
+#endif
+        float* so = en.std_out + pix * en.ld_std;
+        if (en.ld_std == 4 && 3 + nv >= 4 && ((uintptr_t)en.std_out & 15) == 0) *reinterpret_cast<float4*>(so) = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        else {
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            if (c < 3 + nv && c < en.ld_std) so[c] = rec[c];
+        }
+      }
     }
   }
+  for (int c = used; c < c_pad; ++c) mine[c] = Elem<T>::from_f32(0.f);      // padding channels of the network input
   __syncthreads();
   // the tile leaves as 16-byte vectors: pixel row = c_pad elements
   constexpr int N = Elem<T>::PER16;

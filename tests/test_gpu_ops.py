@@ -437,14 +437,19 @@ def test_conv_transpose_3x3(eng, dtype, B, H, W, cin, cout, form, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("pool,stride,H,W", [(3, 2, 16, 16), (3, 2, 10, 14), (2, 2, 8, 12)])
-def test_maxpool(eng, dtype, pool, stride, H, W):
+@pytest.mark.parametrize("accum", [False, True])
+@pytest.mark.parametrize("pool,stride,H,W", [(3, 2, 16, 16), (3, 2, 10, 14), (2, 2, 8, 12), (3, 2, 9, 13), (3, 2, 1, 5), (2, 2, 7, 11), (3, 3, 9, 10)])
+def test_maxpool(eng, dtype, pool, stride, H, W, accum):
+    """Stride 2 with a 3x3 / 2x2 window runs the specialised kernels (one thread per 2x2 input block in the backward), anything else the generic
+    ones; odd sizes put the SAME padding before the image (pad_before = 1), `accum`: the gradient is added to one already written (a skip)."""
     B, C = 2, 16
     gen = _gen(pool * 10 + H)
     g = eng.Graph("cuda", dtype)
     x = g.tensor(B, H, W, C, relu=True, requires_grad=True)
     y = g.maxpool(x, pool, stride)
     y.mark_grad_written()
+    if accum:
+        x.mark_grad_written()
     g.build_backward()
     g.finalize()
     xv = representable(torch.relu(torch.randn(B, H, W, C, generator=gen, dtype=torch.float64)) + 0.0, dtype)
@@ -456,10 +461,13 @@ def test_maxpool(eng, dtype, pool, stride, H, W):
     G = representable(torch.randn(yo.shape, generator=gen, dtype=torch.float64), dtype)
     fill(y.grad(), G)
     (gx,) = torch.autograd.grad((yo * G).sum(), [xo])
+    g0 = representable(torch.randn(B, H, W, C, generator=gen, dtype=torch.float64), dtype) if accum else 0.0
+    if accum:
+        fill(x.grad(), g0)
     g.run(g.bwd_ops)
     torch.cuda.synchronize()
     # exact ties only happen at 0 (ReLU), where the mask kills the gradient anyway
-    check("dx", read(x.grad()), gx * (xv > 0), {"bf16": 2e-3, "f16": 3e-4, "f32": 1e-6}[dtype])
+    check("dx", read(x.grad()), g0 + gx * (xv > 0), {"bf16": 4e-3 if accum else 2e-3, "f16": 5e-4 if accum else 3e-4, "f32": 1e-6}[dtype])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
