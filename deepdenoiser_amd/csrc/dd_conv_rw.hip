@@ -24,6 +24,7 @@ struct RwP {
 };
 
 typedef uint32_t rw_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t rw_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int RW_TW = 16, RW_TH = 8, RW_PW = RW_TW + 2, RW_PH = RW_TH + 2;      // tile and haloed tile
 constexpr int RW_CH = (RW_PW * RW_PH + 7) / 8;                                 // 23 chunks of 8 pixels per 64-channel slice
 constexpr int RW_SLICE = RW_CH * 1024, RW_BUF = 2 * RW_SLICE;                  // 46 KiB per buffer
@@ -220,11 +221,20 @@ template <int KC> struct RfGeo {
 
 // NW = waves per workgroup: 8 (blocks of 4 output-channel tiles = 64 channels) or 12 (3 per SIMD, <= 168 registers: blocks of 6 tiles = 96
 // channels -- the balanced form of the 96-channel forward, whose 6 + 2 wave kernel above loads two SIMDs with two compute waves and two with one)
-template <typename T, int KC, int NW>
+// AUX != 0 (round 4): an output-shaped operand next to the results, on the same waves -- 1: the ReLU-backward data gradient (y = conv(x) * (aux > 0),
+// no bias), 2: a residual (y = act(round(conv(x) + bias) + aux): the second half of a conv over a channel concat).  The operand's tile (16 x TH
+// pixels of the output block's channels, 64-channel slices of 1 KiB chunks like the image) is fetched by LDS-DMA next to the image, one tile
+// ahead, and an output row reads its 8 bytes from LDS: the compute waves still issue no vector loads of their own, so their vmcnt waits for
+// nothing but the DMA at the tile barrier (the 6 + 2 wave kernel above parks on its mask loads half of the time: profiles/r04_a_sq_table.txt).
+// Measured (cfg-2 step, same box): 96 -> 96 masked data gradient at 64 x 64, B = 128: 95 - 103 -> 82 us; 96 -> 192: 206 -> 159 us.
+template <typename T, int KC, int NW, int AUX = 0>
 __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using G = RfGeo<KC>;
+  constexpr bool MASKED = AUX != 0;      // (an aux tile is staged; AUX says what an output row does with it)
   constexpr int CT = NW / 2, NPIECE = (G::NCHUNK + NW - 1) / NW;      // output-channel tiles per block; DMA pieces per wave and tile
+  constexpr int MCH = DD_TILE * G::TH / 8, MSL = (CT * 16 + 63) / 64;      // mask tile: chunks of 8 pixels per slice, 64-channel slices
+  constexpr int MBUF = MSL * MCH * 1024, NMP = MASKED ? (MSL * MCH + NW - 1) / NW : 0;
   constexpr int PW = G::PW, RH = G::TH / 2, PHW = RH + 2;      // a wave's RH output rows need RH + 2 haloed rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       const int sl = id >= G::CH ? 1 : 0, c = id - sl * G::CH;
       const int pix = c * 8 + rr;
       const int py = (pix * 3641) >> 16, px = pix - py * PW;
-      const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = sl * 64 + ls * 8;
+      const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = sl * 64 + ((lane & 7) ^ rr) * 8;      // (all from the opaque copy: see above)
 #ifdef RW_EXP_NO_DMA
       const bool ok = false;      // (knock-out build: every chunk comes from the zero page -- what the kernel costs without its input traffic)
 #else
@@ -296,9 +306,26 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       rw_dma_1k(ok ? src : zero, buf + sl * G::SLICE + c * 1024);
     }
   };
+  const char* M = reinterpret_cast<const char*>(a.mask);
+  auto mpiece = [&](int k, const RwTile& t, unsigned mbuf) {      // chunk id = k*NW + wave (< MSL * MCH): slice id / MCH, pixels (id % MCH)*8 + r of the tile
+    const int id = k * NW + wave;
+    if (MASKED && id < MSL * MCH) {      // wave-uniform
+      int rr = r;
+      asm volatile("" : "+v"(rr));
+      const int sl = id / MCH, c = id - sl * MCH;
+      const int pix = c * 8 + rr, gy = t.y0 + (pix >> 4), gx = t.x0 + (pix & 15);
+      const int chl = sl * 64 + ((lane & 7) ^ rr) * 8, ch = blk * (CT * 16) + chl;      // (from the opaque copy: nothing here is hoisted out of the tile loop)
+      const bool ok = t.live && chl < CT * 16 && ch < a.n && gy < a.H && gx < a.W;
+      const char* src = M + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldmask + ch) * 2;
+      rw_dma_1k(ok ? src : zero, mbuf + id * 1024);
+    }
+  };
+  const unsigned mask_base = lds_base + 2 * G::BUF;
   RwTile cur = tile_at(tile0);
 #pragma unroll
   for (int k = 0; k < NPIECE; ++k) piece(k, cur, lds_base);
+#pragma unroll
+  for (int k = 0; k < NMP; ++k) mpiece(k, cur, mask_base);
 
   // ---- compute: output-channel tile (wave & 3) of block blk, output rows RH*(wave >> 2) .. + RH - 1
   const int li = lane & 15, q = lane >> 4;
@@ -320,7 +347,13 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
   }
   float bv[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bv[e] = (a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
+  for (int e = 0; e < 4; ++e) bv[e] = (AUX != 1 && a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
+  // this lane's 8 bytes of the mask tile: pixel (RH*half + y)*16 + li -> chunk 2*(RH*half + y) + li/8, row li%8; channels (wave % CT)*16 + 4q of the block
+  unsigned m_off = 0;
+  if (MASKED) {
+    const int c4l = (wave % CT) * 16 + q * 4, rr = li & 7;
+    m_off = mask_base + ((c4l >> 6) * MCH + half * RH * 2 + (li >> 3)) * 1024 + rr * 128 + (((((c4l & 63) >> 3)) ^ rr) << 4) + ((c4l >> 2) & 1) * 8;
+  }
   unsigned d0[8];      // haloed pixel (RH*half + yy)*18 + dx + li: the row offset of the half is folded into the bases
 #pragma unroll
   for (int c = 0; c < 8; ++c) d0[c] = lds_base + (half * RH * PW + li) * DD_LDS_ROW + ((q ^ ((half * RH * PW + li + c) & 7)) << 4);
@@ -333,10 +366,12 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's chunks of `tile` have landed (and its stores of the previous one)
     __syncthreads();
     const RwTile nxt = tile_at(tile + a.ksplit);
-    const unsigned nbuf = lds_base + (sel ^ 1) * G::BUF;
+    const unsigned nbuf = lds_base + (sel ^ 1) * G::BUF, nmbuf = mask_base + (sel ^ 1) * MBUF;
     if (!active) {
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) piece(k, nxt, nbuf);
+#pragma unroll
+      for (int k = 0; k < NMP; ++k) mpiece(k, nxt, nmbuf);
       cur = nxt;
       continue;
     }
@@ -344,17 +379,32 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
     T* yp = Y + (((long)cur.b * a.H + cur.y0 + half * RH) * a.W + cur.x0 + li) * a.ldy + c4;
     f32x4_t acc[4];
     constexpr int FR = 3 * KC, NF = PHW * FR, RING = NW == 8 ? 6 : 2, AHEAD = RING - 1;      // (12 waves: 168 registers, 108 of them weights)
-    uint4 ring[RING];
+    // (native vectors, and for RING == 2 two named registers: in the AUX builds an array of HIP uint4 structs was left in scratch memory)
+    rw_u32x4 ring[RING], r0 = {0u, 0u, 0u, 0u}, r1 = r0;
+    auto slot = [&](int i) -> rw_u32x4& { if constexpr (RING == 2) return (i & 1) ? r1 : r0; else return ring[i % RING]; };
     auto frag = [&](int f) {
       const int yy = f / FR, j = f - FR * yy, dx = j / KC, kc = j - KC * dx, C = yy * PW + dx;
-      return rw_lds16((d0[C & 7] ^ ((kc & 1) << 6)) + (kc >> 1) * G::SLICE + C * DD_LDS_ROW);
+      return *reinterpret_cast<const __attribute__((address_space(3))) rw_u32x4*>((d0[C & 7] ^ ((kc & 1) << 6)) + (kc >> 1) * G::SLICE + C * DD_LDS_ROW);
+    };
+    uint2 mv = uint2{0u, 0u};
+    auto read_mask = [&](int y) {
+      const rw_u32x2 m = *reinterpret_cast<const __attribute__((address_space(3))) rw_u32x2*>(m_off + y * 2048);
+      mv = uint2{m[0], m[1]};
     };
     auto write_row = [&](int y) {
       f32x4_t v = acc[y % 4];
       uint2 o2;
       o2.x = pack2<T>(v[0], v[1]);
       o2.y = pack2<T>(v[2], v[3]);
-      if (a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
+      if (AUX == 1) { o2.x = mask_bf16x2_cmp(o2.x, mv.x); o2.y = mask_bf16x2_cmp(o2.y, mv.y); }
+      if (AUX == 2) {      // the conv result is rounded where the layer-wise path stores it, then the residual is added (as the 6 + 2 wave kernel does)
+        float f8[8], g8[8];
+        unpack8t<T>(uint4{o2.x, o2.y, 0u, 0u}, f8);
+        unpack8t<T>(uint4{mv.x, mv.y, 0u, 0u}, g8);
+        o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
+        o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
+      }
+      if (AUX != 1 && a.relu) { o2.x = relu_bf16x2(o2.x); o2.y = relu_bf16x2(o2.y); }
 #ifdef RW_EXP_NO_STORE
       if (col_ok && cur.y0 + half * RH + y < a.H && o2.x == 0x12345678u) *reinterpret_cast<uint2*>(yp + y * yrow) = o2;      // (knock-out build)
 #else
@@ -362,39 +412,49 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
 #endif
     };
 #pragma unroll
-    for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
+    for (int f = 0; f < AHEAD; ++f) slot(f) = frag(f);
 #pragma unroll
     for (int yy = 0; yy < PHW; ++yy) {
 #pragma unroll
       for (int j = 0; j < FR; ++j) {
         const int f = yy * FR + j, dx = j / KC, kc = j - KC * dx;
 #ifndef RW_EXP_NO_MMA
-        if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
+        if (f + AHEAD < NF) slot(f + AHEAD) = frag(f + AHEAD);
 #endif
         if (j == 0 && yy < RH) acc[yy % 4] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
-        if (j == 2 && yy >= 3) write_row(yy - 3);
+        // (MASKED: the mask is read two fragment steps = 6 MFMAs ahead of its use, and both sit on steps that issue no DMA piece -- the piece's
+        //  address arithmetic and the mask word together were 4 registers over the 168 of a 12-wave workgroup)
+        constexpr int WJ = MASKED ? 6 : 2;
+        static_assert(WJ < FR, "the row store needs its fragment step");
+        if (MASKED && j == WJ - 2 && yy >= 3) read_mask(yy - 3);
+        if (j == WJ && yy >= 3) write_row(yy - 3);
         {      // the DMA pieces of the next tile, spread evenly over the first RW8_DMA_SPAN / 8 of the NF steps (the rest of the tile hides their latency)
-          constexpr int SPAN = NF * RW8_DMA_SPAN / 8 > NPIECE ? NF * RW8_DMA_SPAN / 8 : NF;
-          static_assert(SPAN >= NPIECE, "at most one piece per step");
-          const int k0 = (f * NPIECE + SPAN - 1) / SPAN;
-          if (k0 < NPIECE && (k0 * SPAN) / NPIECE == f) piece(k0, nxt, nbuf);
+          constexpr int NP = NPIECE + NMP;
+          constexpr int SPAN = NF * RW8_DMA_SPAN / 8 > NP ? NF * RW8_DMA_SPAN / 8 : NF;
+          static_assert(SPAN >= NP, "at most one piece per step");
+          const int k0 = (f * NP + SPAN - 1) / SPAN;
+          if (k0 < NP && (k0 * SPAN) / NP == f) { if (k0 < NPIECE) piece(k0, nxt, nbuf); else mpiece(k0 - NPIECE, nxt, nmbuf); }
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifndef RW_EXP_NO_MMA      // (knock-out build: the kernel as a pure mover of its input tiles and output rows)
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int y = yy - dy;
-          if (y >= 0 && y < RH) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], ring[f % RING], acc[y % 4]);
+          if (y >= 0 && y < RH) acc[y % 4] = mma16<T>(wf[dy * 3 + dx][kc], uint4{slot(f)[0], slot(f)[1], slot(f)[2], slot(f)[3]}, acc[y % 4]);
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
-    for (int y = (PHW >= 3 ? PHW - 3 : 0); y < RH; ++y) write_row(y);      // the rows completed by the last haloed rows
+    for (int y = (PHW >= 3 ? PHW - 3 : 0); y < RH; ++y) {      // the rows completed by the last haloed rows
+      if (MASKED) read_mask(y);
+      write_row(y);
+    }
     const int flip = sel ? -G::BUF : G::BUF;
 #pragma unroll
     for (int c = 0; c < 8; ++c) d0[c] += flip;
+    if (MASKED) m_off += sel ? -MBUF : MBUF;
     cur = nxt;
   }
 }
@@ -433,14 +493,20 @@ bool dd_conv_rw_eligible(const dd_conv_args* a) {
   if (!common) return false;
   if (a->cin > 64 && a->cin <= 96 && a->k_pad <= 96) return true;
   // forward on all 8 waves: <= 64 input channels, or 97..128 (two slices, weights 144 registers); nothing but bias / ReLU in the epilogue
-  return on8 && ((a->cin > 16 && a->cin <= 64 && a->k_pad <= 64) || (a->cin > 96 && a->cin <= 128 && a->k_pad <= 128)) && !a->mask &&
-         !(a->flags & DD_ACCUM) && a->n >= 48;
+  // (97..128 input channels: also the ReLU-backward data gradient -- mask tile by LDS-DMA, no bias)
+  static int on8m = -1;
+  if (on8m < 0) { const char* e = getenv("DD_CONV_RW8_MASK"); on8m = e ? atoi(e) : 1; }
+  const bool wide = a->cin > 96 && a->cin <= 128 && a->k_pad <= 128;
+  const bool mask_ok = !a->mask || (on8m && wide && !a->res && !a->bias && !(a->flags & DD_OUT_RELU) && a->n % 8 == 0 && a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0);
+  return on8 && ((a->cin > 16 && a->cin <= 64 && a->k_pad <= 64) || wide) && mask_ok && !(a->flags & DD_ACCUM) && a->n >= 48;
 }
 
-template <typename T, int KC, int NW = 8>
+template <typename T, int KC, int NW = 8, int AUX = 0>
 static void rw8_launch(const RwP& p, hipStream_t stream) {
-  dd_allow_max_lds(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC, NW>));
-  hipLaunchKernelGGL((conv_rw8_kernel<T, KC, NW>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(NW * 64), 2 * (size_t)RfGeo<KC>::BUF, stream, p);
+  constexpr size_t mask_lds = AUX ? 2 * (size_t)((NW / 2 * 16 + 63) / 64) * (DD_TILE * RfGeo<KC>::TH / 8) * 1024 : 0;
+  static_assert(2 * (size_t)RfGeo<KC>::BUF + mask_lds <= 160 * 1024, "LDS");
+  dd_allow_max_lds(reinterpret_cast<const void*>(conv_rw8_kernel<T, KC, NW, AUX>));
+  hipLaunchKernelGGL((conv_rw8_kernel<T, KC, NW, AUX>), dim3((unsigned)(p.nblk * p.ksplit)), dim3(NW * 64), 2 * (size_t)RfGeo<KC>::BUF + mask_lds, stream, p);
 }
 
 int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
@@ -453,7 +519,15 @@ int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
   static int on12 = -1;
   if (on12 < 0) { const char* e = getenv("DD_CONV_RW12"); on12 = e ? atoi(e) : 1; }
   const bool plain_fwd = !a->mask && !a->res && !(a->flags & DD_ACCUM);
-  const bool twelve = on12 && a->cin > 64 && a->cin <= 96 && plain_fwd && a->n >= 48;      // all 12 waves compute (forward only)
+  static int on12m = -1;
+  if (on12m < 0) { const char* e = getenv("DD_CONV_RW12_MASK"); on12m = e ? atoi(e) : 1; }
+  // the ReLU-backward data gradient on all 12 waves: mask tile by LDS-DMA (16-byte pieces: 8-channel groups of the mask rows must be aligned)
+  const bool masked12 = on12 && on12m && a->cin > 64 && a->cin <= 96 && a->mask && !a->res && !a->bias && !(a->flags & (DD_ACCUM | DD_OUT_RELU)) &&
+                        a->n >= 48 && a->n % 8 == 0 && a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0;
+  // ... and the second half of a conv over a channel concat (residual operand, bias / ReLU)
+  const bool res12 = on12 && on12m && a->cin > 64 && a->cin <= 96 && a->res && !a->mask && !(a->flags & DD_ACCUM) && a->n >= 48 && a->n % 8 == 0 &&
+                     a->ldres % 8 == 0 && ((uintptr_t)a->res % 16) == 0;
+  const bool twelve = on12 && a->cin > 64 && a->cin <= 96 && (plain_fwd || masked12 || res12) && a->n >= 48;      // all 12 waves compute
   const bool six = a->cin > 64 && a->cin <= 96 && !twelve;      // 6 compute + 2 I/O waves, any epilogue; else all waves compute, forward only
   const int th = six ? RW_TH : (a->cin <= 64 ? RfGeo<2>::TH : RfGeo<4>::TH);      // (RfGeo<3>::TH == RfGeo<4>::TH == 8)
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, th);
@@ -463,12 +537,18 @@ int dd_conv_rw_launch(const dd_conv_args* a, hipStream_t stream) {
   if (ksplit < 1) ksplit = 1;
   if (ksplit > total) ksplit = total;
   p.ksplit = (int)ksplit;
-  if (twelve) {
+  if (masked12) {
+    if (a->dtype == DD_BF16) rw8_launch<bf16_t, 3, 12, 1>(p, stream); else rw8_launch<f16_t, 3, 12, 1>(p, stream);
+  } else if (res12) {
+    if (a->dtype == DD_BF16) rw8_launch<bf16_t, 3, 12, 2>(p, stream); else rw8_launch<f16_t, 3, 12, 2>(p, stream);
+  } else if (twelve) {
     if (a->dtype == DD_BF16) rw8_launch<bf16_t, 3, 12>(p, stream); else rw8_launch<f16_t, 3, 12>(p, stream);
   } else if (six) {
     if (a->dtype == DD_BF16) rw_launch_flags<bf16_t, 3>(p, stream); else rw_launch_flags<f16_t, 3>(p, stream);
   } else if (a->cin <= 64) {
     if (a->dtype == DD_BF16) rw8_launch<bf16_t, 2>(p, stream); else rw8_launch<f16_t, 2>(p, stream);
+  } else if (a->mask) {
+    if (a->dtype == DD_BF16) rw8_launch<bf16_t, 4, 8, 1>(p, stream); else rw8_launch<f16_t, 4, 8, 1>(p, stream);
   } else {
     if (a->dtype == DD_BF16) rw8_launch<bf16_t, 4>(p, stream); else rw8_launch<f16_t, 4>(p, stream);
   }
