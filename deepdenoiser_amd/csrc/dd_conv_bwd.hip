@@ -24,6 +24,9 @@
 // 64 (one workgroup column per block; dy is re-read per block).
 #include "dd_common.h"
 
+#ifndef BW_DMA_SPAN
+#define BW_DMA_SPAN 8      // eighths of a tile's fragment steps over which the data-gradient waves issue the next tile's DMA pieces
+#endif
 namespace {
 
 struct BwdP {
@@ -246,9 +249,10 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
             if (ACCUM && col_ok && oc.y0 + yy < a.H) oldv[yy % 4] = *reinterpret_cast<const uint2*>(dxp + yy * row_stride);
           }
           if (j == 2 && yy >= 3) write_row(yy - 3);      // (under this row's MFMAs)
-          {      // the NP DMA pieces of the next tile, spread evenly over the NF steps (piece k at step k*NF/NP)
-            const int k0 = (f * NP + NF - 1) / NF;
-            if (k0 < NP && (k0 * NF) / NP == f) piece(k0, on, sel ^ 1);
+          {      // the NP DMA pieces of the next tile, spread evenly over the first BW_DMA_SPAN / 8 of the NF steps (piece k at step k*SPAN/NP)
+            constexpr int SPAN = NF * BW_DMA_SPAN / 8 > NP ? NF * BW_DMA_SPAN / 8 : NP;
+            const int k0 = (f * NP + SPAN - 1) / SPAN;
+            if (k0 < NP && (k0 * SPAN) / NP == f) piece(k0, on, sel ^ 1);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

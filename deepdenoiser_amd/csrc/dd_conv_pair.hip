@@ -13,6 +13,9 @@
 //   * TensorFlow pads every layer with zeros: intermediate pixels outside the image are written as zeros, whatever the first conv gives there.
 #include "dd_common.h"
 
+#ifndef PAIR_DMA_SPAN
+#define PAIR_DMA_SPAN 8      // eighths of the first conv's fragment steps over which the next tile's DMA pieces are issued
+#endif
 namespace {
 
 struct PairP {
@@ -164,8 +167,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairP a) {
           if (j == 0 && yy < RA) acc[yy % 4] = f32x4_t{bv1[0], bv1[1], bv1[2], bv1[3]};
           if (j == 2 && yy >= 3) write_row(yy - 3);
           {      // the DMA pieces of the next tile, spread over this phase
-            const int k0 = (f * NPIECE + NF - 1) / NF;
-            if (k0 < NPIECE && (k0 * NF) / NPIECE == f) piece(k0, nxt, nbuf);
+            constexpr int SPAN = NF * PAIR_DMA_SPAN / 8 > NPIECE ? NF * PAIR_DMA_SPAN / 8 : NPIECE;
+            const int k0 = (f * NPIECE + SPAN - 1) / SPAN;
+            if (k0 < NPIECE && (k0 * SPAN) / NPIECE == f) piece(k0, nxt, nbuf);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(const RwP a) {
 // KC = 2: <= 64 input channels, one 64-channel slice, 16 x 16 tiles (18 x 18 haloed: 41 chunks);  KC = 4: <= 128 input channels, two slices,
 // 16 x 8 tiles (18 x 10 haloed: 2 x 23 chunks) -- either way <= 46 KiB per buffer
 #ifndef RW8_DMA_SPAN
-#define RW8_DMA_SPAN 8      // eighths of a tile's fragment steps over which the next tile's DMA pieces are issued (8 = the whole tile)
+#define RW8_DMA_SPAN 2      // eighths of a tile's fragment steps over which the next tile's DMA pieces are issued (round 4: 8 -> 2, the 64-channel forward 150 -> 125 us: a piece issued late in the tile is still in flight at the tile barrier; 0 = all at once and 1 measured slightly worse than 2 - 3)
 #endif
 template <int KC> struct RfGeo {
   static constexpr int NS = (KC + 1) / 2, TH = NS == 1 ? DD_TILE : DD_TILE / 2, PW = DD_TILE + 2, PH = TH + 2;
@@ -430,10 +430,16 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
         if (j == WJ && yy >= 3) write_row(yy - 3);
         {      // the DMA pieces of the next tile, spread evenly over the first RW8_DMA_SPAN / 8 of the NF steps (the rest of the tile hides their latency)
           constexpr int NP = NPIECE + NMP;
-          constexpr int SPAN = NF * RW8_DMA_SPAN / 8 > NP ? NF * RW8_DMA_SPAN / 8 : NF;
-          static_assert(SPAN >= NP, "at most one piece per step");
-          const int k0 = (f * NP + SPAN - 1) / SPAN;
-          if (k0 < NP && (k0 * SPAN) / NP == f) { if (k0 < NPIECE) piece(k0, nxt, nbuf); else mpiece(k0 - NPIECE, nxt, nmbuf); }
+          if constexpr (RW8_DMA_SPAN == 0) {      // (experiment: all pieces back to back before the first fragment step)
+            if (f == 0) {
+#pragma unroll
+              for (int k = 0; k < NP; ++k) { if (k < NPIECE) piece(k, nxt, nbuf); else mpiece(k - NPIECE, nxt, nmbuf); }
+            }
+          } else {
+            constexpr int SPAN = NF * RW8_DMA_SPAN / 8 > NP ? NF * RW8_DMA_SPAN / 8 : NP;
+            const int k0 = (f * NP + SPAN - 1) / SPAN;
+            if (k0 < NP && (k0 * SPAN) / NP == f) { if (k0 < NPIECE) piece(k0, nxt, nbuf); else mpiece(k0 - NPIECE, nxt, nmbuf); }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifndef RW_EXP_NO_MMA      // (knock-out build: the kernel as a pure mover of its input tiles and output rows)

@@ -39,6 +39,9 @@ extern "C" int dd_debug_wphases(unsigned long long* out16, int reset) {
 #define WPHASE_ADD(i, a, b)
 #endif
 
+#ifndef WG_DMA_SPAN
+#define WG_DMA_SPAN 8      // eighths of a tile's steps over which the next tile's DMA pieces are issued
+#endif
 namespace {
 
 struct WgradP {
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
         if (kp == c) {
 #pragma unroll
           for (int k = 0; k < NP; ++k)
-            if ((k * NSTEP) / NP == c * HSTEP + hs) piece(k, on, sel ^ 1);
+            if ((k * (NSTEP * WG_DMA_SPAN / 8 > 0 ? NSTEP * WG_DMA_SPAN / 8 : 1)) / NP == c * HSTEP + hs) piece(k, on, sel ^ 1);
         }
 #endif
       if (i == (MODE == 0 ? 4 : 0) && bias_wave) {      // bias gradient from the dy fragments in registers
