@@ -18,7 +18,7 @@ MAX_FEATURES, MAX_COMBINED = 32, 8
 SYMBOLS = (
     "dd_version", "dd_last_error", "dd_pack_weights", "dd_pack_weights_batched", "dd_conv_igemm", "dd_conv_wgrad", "dd_colsum",
     "dd_maxpool_fwd", "dd_maxpool_bwd", "dd_avgpool", "dd_prepare_feature", "dd_gather_input",
-    "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
+    "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_kpcn_hidden_fwd", "dd_kpcn_hidden_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
@@ -245,6 +245,8 @@ def load():
     lib.dd_gather_input.argtypes = [vp, i, i, vp, i, i, i, i, i, i, vp]
     lib.dd_kpcn_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
     lib.dd_kpcn_bwd.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, i, i, vp]
+    lib.dd_kpcn_hidden_fwd.argtypes = [vp, i, vp, i, i, vp, i, vp, vp, i, i, i, i, i, i, vp]
+    lib.dd_kpcn_hidden_bwd.argtypes = [vp, i, vp, i, i, vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
     lib.dd_compose_pack.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
     lib.dd_compose_blend_fwd.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     lib.dd_compose_blend_bwd.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, i, vp, i, vp, i, i, i, i, i, i, vp]

@@ -24,6 +24,9 @@
 // 64 (one workgroup column per block; dy is re-read per block).
 #include "dd_common.h"
 
+#ifndef CBW_DF_RING
+#define CBW_DF_RING 2      // the weight-gradient role's ring of dy fragments (2: one step ahead)
+#endif
 #ifndef BW_DMA_SPAN
 #define BW_DMA_SPAN 8      // eighths of a tile's fragment steps over which the data-gradient waves issue the next tile's DMA pieces
 #endif
@@ -317,23 +320,34 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       if (!active) continue;
       // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each; the dy fragment of step n+1 and (during taps 4..7) the x fragments of the next
       // row pair are requested before the MFMAs of step n.  sched_barriers keep hipcc from hoisting a whole row pair's 26 reads (52 registers).
-      uint4 xf[2][4], df[2];
+      constexpr int DFR = CBW_DF_RING, DFA = DFR - 1;      // dy fragments requested DFA steps ahead
+      uint4 xf[2][4], df[DFR];
 #pragma unroll
       for (int i = 0; i < 4; ++i) xf[0][i] = x_frag(0, i);
-      df[0] = dy_frag(0);
+#pragma unroll
+      for (int n = 0; n < DFA; ++n) df[n] = dy_frag(n);
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int step = s * 9 + t;
-        if (step + 1 < 72) df[(step + 1) & 1] = dy_frag(step + 1);
+        if (step + DFA < 72) df[(step + DFA) % DFR] = dy_frag(step + DFA);
+#ifdef CBW_EXP_HALF_X
+        if (s + 1 < 8 && t >= 4 && t < 6) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
+#else
         if (s + 1 < 8 && t >= 4 && t < 8) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#ifdef CBW_EXP_HALF_MMA
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], df[step & 1]);
+        for (int i = 0; i < 2; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], df[step % DFR]);
+#else
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], df[step % DFR]);
+#endif
         if (t == 4 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel wr*16 + li per lane
           float f[8];
-          unpack8t<T>(df[step & 1], f);
+          unpack8t<T>(df[step % DFR], f);
           bsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
 #ifndef CBW_EXP_ONE_BARRIER_W

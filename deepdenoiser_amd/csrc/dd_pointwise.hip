@@ -748,9 +748,47 @@ extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, i
 }
 
 // ------------------------------------------------------------------------------------------------ kernel prediction
-template <typename T, int KS, bool VEC>
+// The k*k logits of a pixel, either read from the tensor the last 1x1 layer wrote (storage type T), or -- HID -- computed here in fp32 from that
+// layer's INPUT: logits[t] = bb[t] + sum_k hid[k] * wb[k * ldw + t]  (AdjustNumberOfChannels' second conv, Architecture.py:237-244, with the fp32
+// master weights).  A logit of magnitude 50 stored in bf16 is off by up to 0.125, its softmax weight by 13 %: the layer-wise head of the
+// half-precision programs (Tiramisu outputs, COMBINED tuples: what the fused head of csrc/dd_head.hip does not take) keeps them in registers.
+// Every thread reads the same weights: scalar loads through the constant cache.
+template <typename T, int K2, int K2P, bool VEC, bool HID>
+__device__ __forceinline__ void kpcn_logits(const T* __restrict__ row, int kh, const float* __restrict__ wb, int ldw, const float* __restrict__ bb, float (&w)[K2P]) {
+  constexpr int N = Elem<T>::PER16;
+  if (HID) {
+#pragma unroll
+    for (int t = 0; t < K2; ++t) w[t] = bb[t];
+    for (int k0 = 0; k0 < kh; k0 += N) {      // (the row is padded to whole 16-byte vectors: ld % N == 0, host-checked)
+      float h8[N];
+      vload<T>(row + k0, h8);
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        if (k0 + e < kh) {
+          const float* wr = wb + (long)(k0 + e) * ldw;
+#pragma unroll
+          for (int t = 0; t < K2; ++t) w[t] = fmaf(h8[e], wr[t], w[t]);
+        }
+      }
+    }
+  } else if (VEC) {
+#pragma unroll
+    for (int v = 0; v < K2P / N; ++v) {
+      float t8[N];
+      vload<T>(row + v * N, t8);
+#pragma unroll
+      for (int e = 0; e < N; ++e) w[v * N + e] = t8[e];
+    }
+  } else {     // COMBINED tuples: member j's logits start at channel j * K2, not 16-byte aligned
+#pragma unroll
+    for (int t = 0; t < K2; ++t) w[t] = ld1<T>(row + t);
+  }
+}
+
+template <typename T, int KS, bool VEC, bool HID>
 __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
-                                float* __restrict__ out, int ldo, int B, int H, int W) {
+                                float* __restrict__ out, int ldo, int B, int H, int W,
+                                int kh, const float* __restrict__ wb, int ldw, const float* __restrict__ bb) {
   constexpr int K2 = KS * KS, P = (KS - 1) / 2;
   const long total = (long)B * H * W;
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -762,18 +800,7 @@ __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const 
   constexpr int N = Elem<T>::PER16, K2P = (K2 + N - 1) / N * N;      // logits are read as 16-byte vectors (ldl >= K2P, checked by the host)
   float w[K2P];
   float mx = -INFINITY;
-  if (VEC) {
-#pragma unroll
-    for (int v = 0; v < K2P / N; ++v) {
-      float t8[N];
-      vload<T>(logits + i * ldl + v * N, t8);
-#pragma unroll
-      for (int e = 0; e < N; ++e) w[v * N + e] = t8[e];
-    }
-  } else {     // COMBINED tuples: member j's logits start at channel j * K2, not 16-byte aligned
-#pragma unroll
-    for (int t = 0; t < K2; ++t) w[t] = ld1<T>(logits + i * ldl + t);
-  }
+  kpcn_logits<T, K2, K2P, VEC, HID>(logits + i * ldl, kh, wb, ldw, bb, w);
 #pragma unroll
   for (int t = 0; t < K2; ++t) mx = fmaxf(mx, w[t]);
   float sum = 0.f;
@@ -786,10 +813,10 @@ __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const 
   for (int a = 0; a < KS; ++a) {
     const int sy = sym_index(y + a - P, H);
 #pragma unroll
-    for (int bb = 0; bb < KS; ++bb) {
-      const int sx = sym_index(x + bb - P, W);
+    for (int bb2 = 0; bb2 < KS; ++bb2) {
+      const int sx = sym_index(x + bb2 - P, W);
       const float* s = img + ((long)sy * W + sx) * ldsrc;
-      const float wt = w[a * KS + bb] * inv;
+      const float wt = w[a * KS + bb2] * inv;
       o0 += wt * s[0]; o1 += wt * s[1]; o2 += wt * s[2];
     }
   }
@@ -797,10 +824,10 @@ __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const 
   o[0] = o0; o[1] = o1; o[2] = o2;
 }
 
-template <typename T, int KS, bool VEC>
+template <typename T, int KS, bool VEC, bool HID>
 __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
                                 const float* __restrict__ dout, int lddo, T* __restrict__ dlogits, int lddl, int dl_pad,
-                                int B, int H, int W) {
+                                int B, int H, int W, int kh, const float* __restrict__ wb, int ldw, const float* __restrict__ bb) {
   constexpr int K2 = KS * KS, P = (KS - 1) / 2;
   const long total = (long)B * H * W;
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -812,18 +839,7 @@ __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const 
   constexpr int N = Elem<T>::PER16, K2P = (K2 + N - 1) / N * N;
   float w[K2P], dw[K2];
   float mx = -INFINITY;
-  if (VEC) {
-#pragma unroll
-    for (int v = 0; v < K2P / N; ++v) {
-      float t8[N];
-      vload<T>(logits + i * ldl + v * N, t8);
-#pragma unroll
-      for (int e = 0; e < N; ++e) w[v * N + e] = t8[e];
-    }
-  } else {     // COMBINED tuples: member j's logits start at channel j * K2, not 16-byte aligned
-#pragma unroll
-    for (int t = 0; t < K2; ++t) w[t] = ld1<T>(logits + i * ldl + t);
-  }
+  kpcn_logits<T, K2, K2P, VEC, HID>(logits + i * ldl, kh, wb, ldw, bb, w);
 #pragma unroll
   for (int t = 0; t < K2; ++t) mx = fmaxf(mx, w[t]);
   float sum = 0.f;
@@ -837,10 +853,10 @@ __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const 
   for (int a = 0; a < KS; ++a) {
     const int sy = sym_index(y + a - P, H);
 #pragma unroll
-    for (int bb = 0; bb < KS; ++bb) {
-      const int sx = sym_index(x + bb - P, W);
+    for (int bb2 = 0; bb2 < KS; ++bb2) {
+      const int sx = sym_index(x + bb2 - P, W);
       const float* s = img + ((long)sy * W + sx) * ldsrc;
-      const int t = a * KS + bb;
+      const int t = a * KS + bb2;
       w[t] *= inv;
       dw[t] = g0 * s[0] + g1 * s[1] + g2 * s[2];
       dot += w[t] * dw[t];
@@ -868,22 +884,26 @@ __global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const 
   }
 }
 
+// hid != NULL: the logits are computed in the kernel from `hid` (kh channels, rows of ldl elements) and (wb, ldw, bb); `logits` is not read
 template <typename T>
 static int kpcn_dispatch(bool fwd, const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
-                         void* out, int ldo, int pad, int B, int H, int W, int ks, hipStream_t s) {
+                         void* out, int ldo, int pad, int B, int H, int W, int ks, hipStream_t s,
+                         const void* hid = nullptr, int kh = 0, const float* wb = nullptr, int ldw = 0, const float* bb = nullptr) {
   const long total = (long)B * H * W;
   const dim3 g(grid_for(total, 128)), blk(128);
   // 16-byte vector path: the logits (and, backward, the logit gradients) of this call start 16-byte aligned and are padded to whole vectors
   constexpr int n = Elem<T>::PER16;
   const int k2p = (ks * ks + n - 1) / n * n;
-  bool vec = ((uintptr_t)logits % 16) == 0 && ldl % n == 0 && ldl >= k2p;
-  if (!fwd) vec = vec && ((uintptr_t)out % 16) == 0 && ldo % n == 0 && pad % n == 0 && pad >= k2p;
-#define KP_LAUNCH(K, V)                                                                                                        \
-    if (fwd) hipLaunchKernelGGL((kpcn_fwd_kernel<T, K, V>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, (float*)out, ldo, B, H, W); \
-    else hipLaunchKernelGGL((kpcn_bwd_kernel<T, K, V>), g, blk, 0, s, src, ldsrc, (const T*)logits, ldl, dout, lddo, (T*)out, ldo, pad, B, H, W);
+  bool vec = hid ? true : (((uintptr_t)logits % 16) == 0 && ldl % n == 0 && ldl >= k2p);      // (the logit READS; hid rows are always vector-aligned)
+  if (!fwd) vec = ((uintptr_t)out % 16) == 0 && ldo % n == 0 && pad % n == 0 && pad >= k2p && vec;
+  const T* in = (const T*)(hid ? hid : logits);
+#define KP_LAUNCH(K, V, HD)                                                                                                    \
+    if (fwd) hipLaunchKernelGGL((kpcn_fwd_kernel<T, K, V, HD>), g, blk, 0, s, src, ldsrc, in, ldl, (float*)out, ldo, B, H, W, kh, wb, ldw, bb); \
+    else hipLaunchKernelGGL((kpcn_bwd_kernel<T, K, V, HD>), g, blk, 0, s, src, ldsrc, in, ldl, dout, lddo, (T*)out, ldo, pad, B, H, W, kh, wb, ldw, bb);
 #define KP_CASE(K)                                                                                                             \
   case K:                                                                                                                      \
-    if (vec) { KP_LAUNCH(K, true) } else { KP_LAUNCH(K, false) }                                                               \
+    if (hid) { if (vec) { KP_LAUNCH(K, true, true) } else { KP_LAUNCH(K, false, true) } }                                      \
+    else if (vec) { KP_LAUNCH(K, true, false) } else { KP_LAUNCH(K, false, false) }                                            \
     break;
   switch (ks) {
     KP_CASE(3) KP_CASE(5) KP_CASE(7)
@@ -904,6 +924,22 @@ extern "C" int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int 
                            void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream) {
   DD_REQUIRE(src && logits && dout && dlogits && ldl >= ksize * ksize && dl_pad <= lddl, "dd_kpcn_bwd: bad arguments");
   DD_DISPATCH_DTYPE(dtype, T, return kpcn_dispatch<T>(false, src, ldsrc, logits, ldl, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream)));
+  return DD_ERR_INVALID;
+}
+static bool kpcn_hidden_ok(const void* hid, int ldh, int kh, const float* wb, int ldw, const float* bb, int ksize, int dtype) {
+  const int n = dtype == DD_F32 ? 4 : 8;
+  return hid && wb && bb && kh > 0 && ldh % n == 0 && ldh >= (kh + n - 1) / n * n && ((uintptr_t)hid % 16) == 0 && ldw >= ksize * ksize;
+}
+extern "C" int dd_kpcn_hidden_fwd(const float* src, int ldsrc, const void* hid, int ldh, int kh, const float* wb, int ldw, const float* bb,
+                                  float* out, int ldo, int B, int H, int W, int ksize, int dtype, dd_stream stream) {
+  DD_REQUIRE(src && out && kpcn_hidden_ok(hid, ldh, kh, wb, ldw, bb, ksize, dtype), "dd_kpcn_hidden_fwd: bad arguments (hid rows must be 16-byte vectors, ldw >= k*k)");
+  DD_DISPATCH_DTYPE(dtype, T, return kpcn_dispatch<T>(true, src, ldsrc, nullptr, ldh, nullptr, 0, out, ldo, 0, B, H, W, ksize, S(stream), hid, kh, wb, ldw, bb));
+  return DD_ERR_INVALID;
+}
+extern "C" int dd_kpcn_hidden_bwd(const float* src, int ldsrc, const void* hid, int ldh, int kh, const float* wb, int ldw, const float* bb,
+                                  const float* dout, int lddo, void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream) {
+  DD_REQUIRE(src && dout && dlogits && dl_pad <= lddl && kpcn_hidden_ok(hid, ldh, kh, wb, ldw, bb, ksize, dtype), "dd_kpcn_hidden_bwd: bad arguments");
+  DD_DISPATCH_DTYPE(dtype, T, return kpcn_dispatch<T>(false, src, ldsrc, nullptr, ldh, dout, lddo, dlogits, lddl, dl_pad, B, H, W, ksize, S(stream), hid, kh, wb, ldw, bb));
   return DD_ERR_INVALID;
 }
 

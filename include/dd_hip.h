@@ -225,6 +225,15 @@ int dd_kpcn_fwd(const float* src, int ldsrc, const void* logits, int ldl, float*
                 int B, int H, int W, int ksize, int dtype, dd_stream stream);
 int dd_kpcn_bwd(const float* src, int ldsrc, const void* logits, int ldl, const float* dout, int lddo,
                 void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream);
+/* The same with the logits computed IN the kernel, in fp32, from the input of AdjustNumberOfChannels' second 1x1 layer (Architecture.py:237-244):
+ * logits[t] = bb[t] + sum_k hid[k] * wb[k * ldw + t], hid [B,H,W,ldh] of dtype (kh channels, post-ReLU), wb / bb the fp32 master variables
+ * (TensorFlow layout [kh][ldw]; a COMBINED tuple's member j passes wb + j*k*k, bb + j*k*k).  What the layer-wise head of the half-precision
+ * programs uses: a logit of magnitude 50 rounded to bf16 moves its softmax weight by up to 13 %.  The backward writes d logits (dtype) for the
+ * weight / data gradient launches of that layer, exactly as dd_kpcn_bwd does. */
+int dd_kpcn_hidden_fwd(const float* src, int ldsrc, const void* hid, int ldh, int kh, const float* wb, int ldw, const float* bb,
+                       float* out, int ldo, int B, int H, int W, int ksize, int dtype, dd_stream stream);
+int dd_kpcn_hidden_bwd(const float* src, int ldsrc, const void* hid, int ldh, int kh, const float* wb, int ldw, const float* bb,
+                       const float* dout, int lddo, void* dlogits, int lddl, int dl_pad, int B, int H, int W, int ksize, int dtype, dd_stream stream);
 
 /* ---- the whole kernel-prediction head of one scale as ONE launch each way: AdjustNumberOfChannels.predict (Architecture.py:237-244:
  * 1x1 conv C -> K + ReLU, 1x1 conv K -> K) + KernelPredictor.predict / KernelPrediction.kernel_prediction (Architecture.py:260-289,

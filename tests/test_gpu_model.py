@@ -37,11 +37,14 @@ def _inputs(oracle, B, H, W, seed=0):
     return feats, labels
 
 
-def _pair(aj, dtype, B, H, W, tj=None):
+def _pair(aj, dtype, B, H, W, tj=None, tweak=None):
     from deepdenoiser_amd.architecture import Architecture
     oracle = OracleArchitecture(aj, dtype=torch.float64, seed=2)
     feats, labels = _inputs(oracle, B, H, W)
     feats = _with_flags(aj, feats, B, H, W)
+    if tweak is not None:      # edits the oracle's variables in place (they are created by the first forward pass) before they are copied to the
+        oracle.predict(feats)  # device: both sides run the same weights
+        tweak(oracle)
     preds_o = oracle.predict(feats)
     arch = Architecture(aj, device="cuda", dtype=dtype)
     prog = arch.program(B, H, W, training_json=tj)

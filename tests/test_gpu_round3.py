@@ -177,10 +177,10 @@ def test_half_precision_full_size_error_against_the_plain_oracle_max_gated(dtype
 
 
 # ---------------------------------------------------------------------------------------------------------------- BASELINE config 3
-def _plain_training_parity(what, aj, B, H, W, dtype, fwd_gate, loss_gate, grad_median_gate, grad_max_gate):
+def _plain_training_parity(what, aj, B, H, W, dtype, fwd_gate, loss_gate, grad_median_gate, grad_max_gate, tweak=None):
     from test_gpu_model import _pair
     tj = configs.bench_training()
-    oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, dtype, B, H, W, tj)
+    oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, dtype, B, H, W, tj, tweak=tweak)
     preds = arch.predict(dev)
     torch.cuda.synchronize()
     worst = max(check("%s %s scale %d %s" % (what, dtype, s, k), dp[k].cpu(), do[k], fwd_gate) for s, (dp, do) in enumerate(zip(preds, preds_o)) for k in do)
@@ -205,8 +205,10 @@ def test_cfg3_full_size_training_step_parity_f32():
 
 # Measured (bf16 / f16): forward 4.4e-2 / 5e-3, loss 2.0e-5 / 9.9e-6, gradient median 0.70 / 0.30, max 1.47 / 0.70 -- the same figures to four
 # digits with DD_CONV_PW=0 DD_CONVT3_S2D_BWD=0 and with every round-3 kernel off (DD_CONV_KS=0 DD_CONVT3_PARITY=0 DD_DENSE_GATHER=0 as well): as
-# for the heavy configuration below, this random 60-layer net turns half-precision logit rounding into large weight changes of the kernel-
-# prediction softmax, whichever kernels run it.  The loss is gated tightly; the gradient gates are sanity bounds.
+# for the heavy configuration below, this random 60-layer net turns half-precision rounding into large weight changes of the kernel-
+# prediction softmax, whichever kernels run it.  The loss is gated tightly; the gradient gates are sanity bounds.  Round 4: with fp32 logits
+# (dd_kpcn_hidden_*) bf16 0.69 / 1.56, f16 0.26 / 0.55 -- unchanged for bf16: the error arrives in the backbone's activations (x logits of ~50);
+# test_cfg3_full_size_half_precision_gradients_with_unit_logits below is the gate that certifies the kernels at this size.
 @pytest.mark.parametrize("dtype,gates", [("bf16", (7e-2, 1e-3, 1.0, 2.5)), ("f16", (1e-2, 1e-3, 0.5, 1.2))])
 def test_cfg3_full_size_half_precision_runs_the_gemm_tile_kernels(dtype, gates):
     """BASELINE config 3 at its real size in the storage types the bench runs it in (256x256, B = 1: 65 536 pixels at the first level, where the
@@ -218,6 +220,31 @@ def test_cfg3_full_size_half_precision_runs_the_gemm_tile_kernels(dtype, gates):
     before, wbefore = lib.dd_conv_pw_count(), lib.dd_wgrad_pw_count()
     _plain_training_parity("cfg-3 256x256", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 1, 256, 256, dtype, *gates)
     assert lib.dd_conv_pw_count() - before >= 4 and lib.dd_wgrad_pw_count() - wbefore >= 2, "the GEMM-tile kernels did not run"
+
+
+def _tame_logits(scale):
+    """Scale the kernel-prediction head's LAST 1x1 layers (kernel and bias) of every scale: the random 60-layer Tiramisu feeds logits of magnitude
+    ~50 into the softmax, where any half-precision rounding of the backbone's activations (0.4 % of 50 = 0.2) moves a softmax weight by tens of
+    percent -- with logits of order 1 the same network measures the kernels, not the conditioning of a random initialisation."""
+    def tweak(oracle):
+        convs = [n for n in oracle.vs.vars if n.startswith("reused_core_architecture/conv2d") and "transpose" not in n and n.endswith("/kernel")]
+        n_scales = 3
+        for n in convs[-2 * n_scales:][1::2]:      # variable-creation order: (1x1 C -> K, 1x1 K -> K) per scale
+            with torch.no_grad():
+                oracle.vs.vars[n].mul_(scale)
+                oracle.vs.vars[n[:-len("kernel")] + "bias"].mul_(scale)
+    return tweak
+
+
+# Round 4 (VERDICT r3 item 3): fp32 logits in the layer-wise head (dd_kpcn_hidden_*) move the heavy configuration's bf16 gradient median 0.65 -> 0.43
+# (fp16 0.11 -> 0.06) but NOT the light one's (0.69 -> 0.69): what reaches the softmax is the backbone's half-precision activations times logits
+# of magnitude 50, not the rounding of the stored logits.  With the head's last layer scaled so that the logits are of order 1 the SAME network,
+# at full size, through the same kernels, is gated at rounding level.
+# Measured (bf16 / f16): forward 7.2e-3 / 9.5e-4, gradient median 2.4e-2 / 1.3e-2, max 5.3e-2 / 5.6e-2 over the 74 tensors (cfg-2's gates: 0.045 / 0.16).
+@pytest.mark.parametrize("dtype,gates", [("bf16", (2e-2, 1e-3, 0.05, 0.12)), ("f16", (3e-3, 1e-3, 0.03, 0.12))])
+def test_cfg3_full_size_half_precision_gradients_with_unit_logits(dtype, gates):
+    _need_gpu()
+    _plain_training_parity("cfg-3 256x256, logits / 32", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 1, 256, 256, dtype, *gates, tweak=_tame_logits(1.0 / 32))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
