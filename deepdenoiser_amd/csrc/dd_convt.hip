@@ -261,6 +261,9 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     ct_dma_x<TH>(a, t, wave, buf + CT_Y_BYTES, lane);
     if (NSD == 1) ct_dma_x<TH>(a, t, wave + 8, buf + CT_Y_BYTES, lane);
   };
+  // (Round 4: three buffers with two tiles in flight and a vmcnt(pieces of one tile) wait at the top measured no faster -- 146 -> 150 us at
+  //  64x64 -> 128x128, 96 -> 64 channels: the loop is not waiting for the DMA.)
+  constexpr int NPW = 5 + (NSD == 1 ? 1 : 0);      // DMA pieces per wave and tile (dma_tile)
   CtTile cur = ct_tile(a, blockIdx.x, total, TH);
   dma_tile(cur, lds_base);
   int sel = 0;
@@ -268,20 +271,32 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     const CtTile nxt = ct_tile(a, tile + a.nwg, total, TH);
+    // ACCUM: the gradient already in dx is requested BEFORE the next tile's DMA pieces and waited for with vmcnt(pieces of this wave): loads return
+    // in order, so nothing of the DMA has to land first.  (Round 3 loaded it with a plain C++ load behind the pieces: hipcc's own s_waitcnt
+    // before its use is vmcnt(0) -- it does not count the inline-asm DMA -- and every tile waited for the whole NEXT tile to arrive, an HBM round
+    // trip per tile.)  The request is inline asm for the same reason; its registers are only touched again behind the explicit wait.
+    const int jj = cur.j0 + (li & 7);
+    const bool ch_ok = c4 < a.cinv && jj < a.W;
+    ct_u32x2 oldr[NG];
+    if (ACCUM) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ii = cur.i0 + 2 * g + (li >> 3);
+        const bool ok = d_active && ch_ok && ii < a.H;
+        const void* op = ok ? static_cast<const void*>(DX + (((long)cur.b * a.H + ii) * a.W + jj) * a.ldo + c4) : static_cast<const void*>(&dd_zero16_v);
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(oldr[g]) : "v"(op) : "memory");
+      }
+    }
     dma_tile(nxt, lds_base + (sel ^ 1) * BUF);
     const unsigned bt = sel * BUF;
     if (d_active) {
       f32x4_t acc[NG];
       uint2 mv[NG], oldv[NG];
-      const int jj = cur.j0 + (li & 7);
-      const bool ch_ok = c4 < a.cinv && jj < a.W;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (MASK) mv[g] = ct_lds8(bt + mb + g * 16 * DD_LDS_ROW);
         oldv[g] = uint2{0u, 0u};
-        const int ii = cur.i0 + 2 * g + (li >> 3);
-        if (ACCUM && ch_ok && ii < a.H) oldv[g] = *reinterpret_cast<const uint2*>(DX + (((long)cur.b * a.H + ii) * a.W + jj) * a.ldo + c4);
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -292,6 +307,18 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
             const uint4 f = ct_lds16(bt + (db[t] ^ ((kc & 1) << 6)) + (kc >> 1) * Y_SLICE + g * 64 * DD_LDS_ROW);
             acc[g] = mma16<T>(wf[t][kc], f, acc[g]);
           }
+      if (ACCUM) {
+        static_assert(NG == 4 || NG == 2, "the wait below names every request register");
+        if constexpr (NG == 4) {
+          if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]));
+          else asm volatile("s_waitcnt vmcnt(5)" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]));
+        } else {
+          if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(oldr[0]), "+v"(oldr[1]));
+          else asm volatile("s_waitcnt vmcnt(5)" : "+v"(oldr[0]), "+v"(oldr[1]));
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) oldv[g] = uint2{oldr[g][0], oldr[g][1]};
+      }
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int ii = cur.i0 + 2 * g + (li >> 3);
