@@ -127,10 +127,13 @@ class VarStore:
         pre = self.qgrad(pre)                  # stored gradients are PRE-activation gradients: masked by the ReLU, then rounded
         return self.q(torch.relu(pre) if relu else pre)
 
-    def conv2d(self, scope, x, filters, k, relu, res=None, split_at=None):
+    def conv2d(self, scope, x, filters, k, relu, res=None, split_at=None, fp32_out=False):
         """tf.layers.conv2d(SAME) [+ res] [+ ReLU].  res / split_at only matter under storage emulation: the half-precision path rounds
         conv + residual ONCE, and runs a 3x3 conv over a > 128-channel skip concat as conv(first part) -> stored partial sum ->
-        conv(second part) + partial sum (engine.Graph.conv)."""
+        conv(second part) + partial sum (engine.Graph.conv).
+        fp32_out (storage emulation only): the layer-wise kernel-prediction head's last 1x1 layer -- its consumer computes the logits itself, in
+        fp32, from the stored input and the fp32 MASTER weights (dd_kpcn_hidden_*), so the value is neither rounded nor multiplied with rounded
+        weights; the layer's gradient launches still read the stored logit gradient and the rounded weights."""
         name = self._layer_name(scope, "conv2d")
         cin = x.shape[3]
         kernel = self.get(name + "/kernel", (k, k, cin, filters), fan_in=k * k * cin, fan_out=k * k * filters)
@@ -141,6 +144,10 @@ class VarStore:
                 y = y + res
             return torch.relu(y) if relu else y
         kq = self.q(kernel)
+        if fp32_out:
+            assert res is None and not relu
+            pre = T.conv2d_same(x, kq, bias, False) + T.conv2d_same(x, kernel - kq, None, False).detach()      # value: x * W; d/dx: through Wq
+            return self.qgrad(pre)
         if (split_at is not None and k == 3 and res is None and cin > 128 and 0 < split_at < cin and split_at % 8 == 0
                 and max(split_at, cin - split_at) <= 128):
             part = self.q(T.conv2d_same(x[..., :split_at], kq[:, :, :split_at], bias, False))
@@ -372,8 +379,11 @@ class OracleArchitecture:
             for i_out, o in enumerate(outs):                          # coarsest first (:573-575)
                 if self.core_name == "U-Net" and i_out < len(outs) - 1:
                     o = vs.branch(o)                                  # (storage emulation: this output also feeds the next transposed conv)
+                # (storage emulation: program.py runs the head layer by layer unless its fused kernel applies -- one tuple member, 3x3 / 5x5 kernels,
+                #  backbone outputs of <= 128 channels in multiples of 8 -- and then the kernel-prediction launch computes the logits in fp32)
+                fused = self.use_kp and len(members) == 1 and self.kernel_size in (3, 5) and all(t.shape[3] % 8 == 0 and t.shape[3] <= 128 for t in outs)
                 o = vs.conv2d(scope, o, self.post_channels, 1, relu=True)
-                o = vs.conv2d(scope, o, self.post_channels, 1, relu=False)
+                o = vs.conv2d(scope, o, self.post_channels, 1, relu=False, fp32_out=vs.storage is not None and self.use_kp and not fused)
                 post.append(o)
             if self.use_multiscale:
                 post = list(reversed(post))                           # :577-579

@@ -498,6 +498,51 @@ def test_kernel_prediction_apply(lib, eng, dtype, ks):
     assert float(dl[..., k2:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("ks,members", [(5, 1), (3, 3), (7, 1)])
+def test_kernel_prediction_from_hidden_fp32_logits(lib, eng, dtype, ks, members):
+    """dd_kpcn_hidden_fwd / _bwd: logits = bb + hid @ wb computed in the launch in fp32 (Architecture.py:237-244 second conv + :260-289), for one
+    member of a tuple (column offset j*k*k into wb / bb, as a COMBINED tuple passes them).  The inputs (hid in the storage type, fp32 weights) are
+    exact, so the outputs are gated at fp32-accumulation level -- where the stored-logit path is gated at the storage type's rounding."""
+    from deepdenoiser_amd import _lib as L
+    B, H, W = 2, 12, 20
+    k2 = ks * ks
+    kh = k2 * members                                   # hidden channels = all members' logits (AdjustNumberOfChannels is K -> K)
+    n = 4 if dtype == "f32" else 8
+    ldh = (kh + n - 1) // n * n
+    gen = _gen(ks * 10 + members)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    code = {"f32": L.DD_F32, "bf16": L.DD_BF16, "f16": L.DD_F16}[dtype]
+    src = torch.randn(B, H, W, 4, generator=gen).cuda()
+    hid = representable(torch.relu(torch.randn(B, H, W, ldh, generator=gen, dtype=torch.float64)), dtype)
+    hid[..., kh:] = 3.0                                 # padding channels of the row must not be read
+    wb = (torch.randn(kh, kh, generator=gen) * 4.0 / kh ** 0.5)
+    bb = torch.randn(kh, generator=gen)
+    hd, wbd, bbd = hid.to(tdt).cuda(), wb.cuda(), bb.cuda()
+    for j in range(members):
+        out = torch.zeros(B, H, W, 3).cuda()
+        L.check(lib.dd_kpcn_hidden_fwd(src.data_ptr(), 4, hd.data_ptr(), ldh, kh, wbd.data_ptr() + 4 * j * k2, kh, bbd.data_ptr() + 4 * j * k2,
+                                       out.data_ptr(), 3, B, H, W, ks, code, None))
+        so = src[..., :3].double().cpu()
+        ho = hid[..., :kh].clone().requires_grad_(True)
+        lo = ho @ wb.double()[:, j * k2:(j + 1) * k2] + bb.double()[j * k2:(j + 1) * k2]
+        oo = T.kernel_prediction(so, lo, ks)
+        check("kp-hidden out", out.cpu(), oo.detach(), 2e-6)
+        G = torch.randn(B, H, W, 3, generator=gen)
+        lo2 = lo.detach().clone().requires_grad_(True)
+        (gl,) = torch.autograd.grad((T.kernel_prediction(so, lo2, ks) * G.double()).sum(), [lo2])
+        ldl = (kh + n - 1) // n * n
+        dl = torch.full((B, H, W, ldl), 7.0, dtype=tdt).cuda()
+        pad = (ldl - j * k2) if j == members - 1 else k2
+        esz = 4 if dtype == "f32" else 2
+        L.check(lib.dd_kpcn_hidden_bwd(src.data_ptr(), 4, hd.data_ptr(), ldh, kh, wbd.data_ptr() + 4 * j * k2, kh, bbd.data_ptr() + 4 * j * k2,
+                                       G.cuda().data_ptr(), 3, dl.data_ptr() + j * k2 * esz, ldl, pad, B, H, W, ks, code, None))
+        torch.cuda.synchronize()
+        check("kp-hidden dlogits", dl[..., j * k2:(j + 1) * k2].cpu(), gl, ROUND[dtype])
+        if j == members - 1:
+            assert float(dl[..., (j + 1) * k2:].float().abs().max()) == 0.0
+
+
 def test_adam_tf_form(lib):
     """dd_adam_step == tf.train.AdamOptimizer update (eps NOT bias-corrected), 4 steps, flat arena."""
     if not torch.cuda.is_available():

@@ -330,6 +330,47 @@ def test_fused_compose_net_matches_the_layerwise_path(dtype, shape, monkeypatch)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("tuple_type,ks", [("SINGLE", 5), ("COMBINED", 3)])
+def test_layerwise_head_fp32_logits_are_closer_to_the_oracle(dtype, tuple_type, ks, monkeypatch):
+    """dd_kpcn_hidden_fwd / _bwd (round 4): the layer-wise head computes its logits in fp32 from the hidden activations and the fp32 master weights
+    of the last 1x1 layer instead of reading the logits that layer stored in bf16 / fp16.  Same network, same inputs: predictions and gradients
+    must not be further from the f64 oracle than with stored logits; SINGLE (K = 25) and COMBINED (3 members, K = 27: unaligned members)."""
+    _need_gpu()
+    from test_gpu_model import _pair
+    B, H, W = 2, 24, 40
+    aj = configs.architecture(tuple_type=tuple_type, filters=(16, 24), convs=1, flag_mode="NONE", kernel_size=ks,
+                              combined={"Diffuse": {"Color": "Diffuse Color", "Direct": "Diffuse Direct", "Indirect": "Diffuse Indirect"}})
+    tj = configs.bench_training()
+
+    def tame(oracle):      # logits of order 1 (see tests/test_gpu_round3.py: _tame_logits)
+        convs = [n for n in oracle.vs.vars if n.startswith("reused_core_architecture/conv2d") and "transpose" not in n and n.endswith("/kernel")]
+        with torch.no_grad():
+            for n in convs[-4:][1::2]:
+                oracle.vs.vars[n].mul_(1.0 / 16)
+                oracle.vs.vars[n[:-len("kernel")] + "bias"].mul_(1.0 / 16)
+
+    monkeypatch.setenv("DD_FUSE_HEAD", "0")
+    err = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DD_KPCN_FP32_LOGITS", mode)
+        oracle, arch, prog, feats, labels, dev, devl, preds_o = _pair(aj, dtype, B, H, W, tj, tweak=tame)
+        assert prog.fp32_logits == (mode == "1") and not prog.fused_head
+        preds = arch.predict(dev)
+        torch.cuda.synchronize()
+        e_pred = max(rel_l2(dp[k].cpu(), do[k]) for dp, do in zip(preds, preds_o) for k in do)
+        _, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
+        prog.train_step(dev, devl)
+        torch.cuda.synchronize()
+        errs = sorted(rel_l2(arch.params.grad(q).cpu() / prog.loss_scale, go) for q, go in zip(arch.params.params, grads_o) if float(go.norm()) > 0)
+        err[mode] = (e_pred, errs[len(errs) // 2], errs[-1])
+    print("layer-wise head %s %s k=%d: stored logits: prediction %.3e gradient median %.3e max %.3e; fp32 logits: prediction %.3e gradient median %.3e max %.3e"
+          % ((dtype, tuple_type, ks) + err["0"] + err["1"]))
+    # predictions: closer (the op itself is gated at 2e-6 against f64: tests/test_gpu_ops.py::test_kernel_prediction_from_hidden_fp32_logits);
+    # the gradients of this tiny random net move by rounding noise either way (median 1.2e-2 / 1.8e-2 bf16): same level, not further than 2x
+    assert err["1"][0] <= 1.05 * err["0"][0] + 1e-4 and err["1"][1] <= 2.0 * err["0"][1] + 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("ks,filters,shape", [(5, (16, 24, 32), (3, 24, 40)), (3, (16, 16), (2, 32, 16)), (5, (64, 96, 128), (1, 32, 32)), (5, (24, 40), (1, 20, 12))])
 def test_fused_kernel_prediction_head_matches_the_layerwise_path(dtype, ks, filters, shape, monkeypatch):
     """csrc/dd_head.hip (1x1 -> ReLU -> 1x1 -> softmax -> k x k filter apply of a scale in one launch, backward with recompute in one more)
@@ -348,6 +389,9 @@ def test_fused_kernel_prediction_head_matches_the_layerwise_path(dtype, ks, filt
     _, grads_o = OT.train_step(oracle, aj, tj, feats, labels, ([], []), 1)
     dev, devl = {k: v.cuda() for k, v in feats.items()}, {k: v.cuda() for k, v in labels.items()}
     runs = {}
+    # the layer-wise reference of this test stores its logits in the storage type and multiplies with the rounded weights, like the fused kernel's
+    # MFMAs do (the fp32-logit layer-wise head of round 4 is compared with the oracle in test_layerwise_head_fp32_logits_are_closer_to_the_oracle)
+    monkeypatch.setenv("DD_KPCN_FP32_LOGITS", "0")
     for fuse in ("0", "1"):
         monkeypatch.setenv("DD_FUSE_HEAD", fuse)
         arch = Architecture(aj, device="cuda", dtype=dtype)

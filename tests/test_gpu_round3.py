@@ -39,8 +39,12 @@ def _emulated_step(aj, tj, dtype, feats, labels, loss_scale):
     return oracle, [{k: v.detach() for k, v in d.items()} for d in preds], float(loss), grads
 
 
-def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate, fwd_median_gate=None, tight=None):
-    """tight = (name prefixes, gate): parameters whose gradient must match at summation-order level (see the bit-faithful test below)."""
+def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate, fwd_median_gate=None, tight=None, conditioned=False):
+    """tight = (name prefixes, gate): parameters whose gradient must match at summation-order level (see the bit-faithful test below).
+    conditioned: a tensor's error is taken relative to max(|g|, |g - g_plain|), g_plain = the plain f64 oracle's gradient: where storage rounding
+    ALONE moves a gradient by more than its own norm (a bias gradient of the compose net that sums to nearly zero: 0.46 of its norm in round 3,
+    19 x in round 4 for the same kernels) the relative error of any half-precision run is unbounded, and the distance the emulation itself travels
+    is the scale that means something."""
     from deepdenoiser_amd.architecture import Architecture
     plain = OracleArchitecture(aj, dtype=torch.float64, seed=2)
     feats, labels = _inputs(plain, B, H, W)
@@ -64,12 +68,15 @@ def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate
         gate("%s %s forward median over %d predictions" % (what, dtype, len(fwd)), fwd[len(fwd) // 2], fwd_median_gate)
     gate("%s %s loss rel err" % (what, dtype), abs(loss - loss_o) / abs(loss_o), loss_gate)
     errs = []
-    for p, go in zip(arch.params.params, grads_o):
+    grads_p = OT.train_step(plain, aj, tj, feats, labels, ([], []), 1)[1] if conditioned else [None] * len(grads_o)
+    for p, go, gp in zip(arch.params.params, grads_o, grads_p):
         got = arch.params.grad(p).double().cpu() / prog.loss_scale
         if float(go.norm()) == 0.0:
             assert float(got.abs().max()) < 1e-6, p.name
             continue
         e = rel_l2(got, go)
+        if gp is not None:
+            e = float((got - go).norm() / max(float(go.norm()), float((go - gp).norm())))
         errs.append((e, p.name))
         if tight is not None and any(p.name.startswith(pre) for pre in tight[0]):
             gate("%s %s gradient %s" % (what, dtype, p.name), e, tight[1])
@@ -125,7 +132,7 @@ def test_small_networks_half_precision_against_the_storage_emulating_oracle(case
         gmed = gmax = None
     # bf16 networks with many tuples: the majority of the predictions must be bit-faithful (fp16: subnormal handling differs from torch's)
     many = dtype == "bf16" and case in ("example_json_single_embedding", "ragged_tile_three_scales", "combined_tuples_kp3", "invert_before_multiscale")
-    _compare(case, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, gmed, gmax, fwd_median_gate=1e-5 if many else None)
+    _compare(case, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, gmed, gmax, fwd_median_gate=1e-5 if many else None, conditioned=True)
 
 
 BIT_FAITHFUL = {
