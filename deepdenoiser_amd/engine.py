@@ -632,7 +632,10 @@ class Graph:
     def pair_eligible(self, x, layer1, layer2):
         return (self.dtype in ("bf16", "f16") and layer1.kind == "conv" and layer2.kind == "conv" and layer1.k == 3 and layer2.k == 3
                 and x.C == layer1.cin and x.Cp <= 64 and 48 < layer1.cout <= 64 and layer1.cout % 16 == 0 and layer2.cin == layer1.cout and layer2.cout <= 64
-                and layer2.cout % 4 == 0 and x.ld % 8 == 0 and x.ch0 % 8 == 0 and os.environ.get("DD_CONV_PAIR", "1") != "0")
+                and layer2.cout % 4 == 0 and x.ld % 8 == 0 and x.ch0 % 8 == 0 and os.environ.get("DD_CONV_PAIR", "0") != "0")
+        # (Off by default since round 4: with the next tile's DMA issued early the single 64 -> 64 launches take 195 us on the 209 tiles of a frame,
+        #  two of them 390 us against the pair kernel's 498 us -- same box, DD_CONV_PAIR=1 -> 0: 407.5 -> 421.1 MPix/s.  The kernel stays tested
+        #  through Graph.conv_pair and reachable with DD_CONV_PAIR=1.)
 
     def conv_transpose2(self, x, layer, out=None, relu=True):
         """tf.layers.conv2d_transpose(2x2, strides 2) + ReLU (UNet.py:54-59)."""
