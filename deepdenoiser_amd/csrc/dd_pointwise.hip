@@ -786,7 +786,7 @@ __device__ __forceinline__ void kpcn_logits(const T* __restrict__ row, int kh, c
 }
 
 template <typename T, int KS, bool VEC, bool HID>
-__global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
+__global__ __launch_bounds__(128) void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
                                 float* __restrict__ out, int ldo, int B, int H, int W,
                                 int kh, const float* __restrict__ wb, int ldw, const float* __restrict__ bb) {
   constexpr int K2 = KS * KS, P = (KS - 1) / 2;
@@ -825,7 +825,7 @@ __global__ void kpcn_fwd_kernel(const float* __restrict__ src, int ldsrc, const 
 }
 
 template <typename T, int KS, bool VEC, bool HID>
-__global__ void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
+__global__ __launch_bounds__(128) void kpcn_bwd_kernel(const float* __restrict__ src, int ldsrc, const T* __restrict__ logits, int ldl,
                                 const float* __restrict__ dout, int lddo, T* __restrict__ dlogits, int lddl, int dl_pad,
                                 int B, int H, int W, int kh, const float* __restrict__ wb, int ldw, const float* __restrict__ bb) {
   constexpr int K2 = KS * KS, P = (KS - 1) / 2;
