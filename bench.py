@@ -54,7 +54,7 @@ def measured_traffic(B, dtype):
             m = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if m.get("tiles_per_gpu_per_step") == B and m.get("dtype") == dtype and "conv_igemm" in m:
+        if m.get("tiles_per_gpu_per_step") == B and m.get("dtype") == dtype and ("conv_igemm" in m or "conv_rw" in m):      # (round 4: every launch of the family is a register-weight kernel)
             # the bench's conv_igemm launch family = the LDS-weight kernels plus the register-weight kernel dd_conv_igemm forwards to (PMC lists
             # them by kernel name): dispatch-weighted mean of the two
             fams = [m[k] for k in ("conv_igemm", "conv_rw") if k in m]

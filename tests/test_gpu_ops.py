@@ -727,7 +727,8 @@ def test_gemm_tile_kernels_on_concat_views(lib, eng, dtype, kind, C, cout, c0, l
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("cin,cmid,cout,H,W,B,relu2", [(64, 64, 64, 128, 128, 2, True), (32, 64, 64, 33, 45, 1, True), (64, 64, 48, 16, 16, 3, False),
                                                          (24, 64, 64, 20, 28, 2, True), (64, 64, 64, 5, 9, 2, True), (64, 64, 64, 256, 270, 1, True)])
-def test_conv_pair_inference_forward(eng, dtype, cin, cmid, cout, H, W, B, relu2):
+def test_conv_pair_inference_forward(eng, dtype, cin, cmid, cout, H, W, B, relu2, monkeypatch):
+    monkeypatch.setenv("DD_CONV_PAIR", "1")      # (off by default since round 4: two single launches are faster; the kernel stays tested)
     gen = _gen(cin * 5 + cout + H)
     g = eng.Graph("cuda", dtype)
     g.training = False
