@@ -65,6 +65,12 @@ CONV_CASES = [
     (3, 3, 16, 24, 24, True, False, False, False),       # cfg-1 first layer
     (1, 320, 320, 8, 8, False, True, False, False),      # Tiramisu transition-down
     (1, 400, 400, 8, 8, False, True, False, False),      # 7 x 7 channel-slice pairs: the weight gradient leaves the LDS-DMA kernel's split table
+    # round 4: the ReLU-backward data gradient on the all-wave register-weight kernels (mask tile by LDS-DMA) -- ragged 16 x 8 tiles, output blocks
+    # that are not full (80 of 96 channels), 72 / 88 channels of depth, the 97..128-channel form with a ragged last tile row
+    (3, 96, 96, 20, 28, True, False, False, True),
+    (3, 80, 72, 9, 33, True, False, False, True),
+    (3, 128, 112, 13, 19, True, False, False, True),
+    (3, 88, 128, 37, 17, True, False, False, True),
     (3, 32, 64, 256, 264, True, False, False, False),    # images of >= 256 rows and a half-filled 64-channel slice: the lanes of the missing channels
                                                          # must stay out of range whatever the image height (a row sentinel of 255 did not: round 3)
 ]
@@ -200,7 +206,7 @@ def test_conv_non_square_batches(eng, k, cin, cout, H, W, B):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("cin,cout,split_at,H,W", [(192, 96, 96, 16, 16), (160, 64, 64, 20, 12)])
+@pytest.mark.parametrize("cin,cout,split_at,H,W", [(192, 96, 96, 16, 16), (160, 64, 64, 20, 12), (192, 80, 96, 21, 27), (168, 96, 80, 9, 35)])      # (round 4: the residual half on the 12-wave kernel, ragged tiles)
 def test_conv_over_skip_concat_runs_as_two_resident_launches(eng, dtype, cin, cout, split_at, H, W):
     """conv(concat[a | b]) = conv_a(a) + conv_b(b): the forward of a > 128-channel 3x3 layer over a U-Net skip concat (engine.Graph.conv,
     split_at); forward, data- and weight-gradients against the oracle as for every other layer (f32: the split is bf16-only, one launch)."""
