@@ -254,6 +254,15 @@ def test_cfg3_full_size_half_precision_gradients_with_unit_logits(dtype, gates):
     _plain_training_parity("cfg-3 256x256, logits / 32", configs.cfg3_tiramisu(filters=(16, 24, 32), convs=4), 1, 256, 256, dtype, *gates, tweak=_tame_logits(1.0 / 32))
 
 
+# Measured (bf16 / f16): forward 4.4e-3 / 6.0e-4, gradient median 1.8e-2 / 8.0e-3, max 6.2e-2 / 2.2e-2 over the 74 tensors.
+@pytest.mark.parametrize("dtype,gates", [("bf16", (1.5e-2, 2e-2, 0.04, 0.15)), ("f16", (2e-3, 3e-3, 0.02, 0.06))])
+def test_cfg3_heavy_filters_gradients_with_unit_logits(dtype, gates):
+    """The heavy Tiramisu (K-streamed kernel, 17 K-slices, 1 216-channel transposed convs) with the head's last layer scaled to logits of order 1:
+    the gradient gate that means something for this configuration (see test_cfg3_full_size_half_precision_gradients_with_unit_logits)."""
+    _need_gpu()
+    _plain_training_parity("cfg-3 heavy 64x64, logits / 32", configs.cfg3_tiramisu(filters=(64, 96, 128), convs=4), 1, 64, 64, dtype, *gates, tweak=_tame_logits(1.0 / 32))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_cfg3_heavy_filters_deep_reduction_parity(dtype):
     """The heavy Tiramisu, F = [64, 96, 128] x 4 (12.9 M parameters), on a 64x64 tile: implicit-GEMM reductions up to K = 9 x 1 088 = 9 792 and
