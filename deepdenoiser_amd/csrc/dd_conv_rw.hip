@@ -295,15 +295,20 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       asm volatile("" : "+v"(rr));      // (keeps the per-piece coordinates from being hoisted out of the tile loop: see csrc/dd_conv_bwd.hip)
       const int sl = id >= G::CH ? 1 : 0, c = id - sl * G::CH;
       const int pix = c * 8 + rr;
-      const int py = (pix * 3641) >> 16, px = pix - py * PW;
+      const int py = (int)(__umul24(pix, 3641) >> 16), px = pix - (int)__umul24(py, PW);
       const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = sl * 64 + ((lane & 7) ^ rr) * 8;      // (all from the opaque copy: see above)
 #ifdef RW_EXP_NO_DMA
       const bool ok = false;      // (knock-out build: every chunk comes from the zero page -- what the kernel costs without its input traffic)
 #else
       const bool ok = t.live && ch < a.cinv && pix < PW * G::PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
 #endif
-      const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ch) * 2;
-      rw_dma_1k(ok ? src : zero, buf + sl * G::SLICE + c * 1024);
+      // tile origin (haloed pixel (0, 0)) as a wave-uniform 64-bit offset + this lane's 32-bit offset inside the haloed tile from full-rate 24-bit
+      // multiply-adds (round 4: the per-lane 64-bit form compiled to five v_mul_lo_u32 and two v_mad_u64_u32 per piece, quarter-rate instructions
+      // worth ~200 issue cycles next to 1 700 cycles of MFMAs per tile and wave -- 28 -> 16 vector instructions per piece, and NO measurable change
+      // in any launch: the pieces' arithmetic is not on these kernels' critical path).  py <= 10, px <= 17: (py W + px) and 2 ldx fit 24 bits.
+      const long base = ((((long)t.b * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * a.ldx) * 2;
+      const unsigned off = __umul24(__umul24(py, a.W) + px, a.ldx * 2) + ch * 2;
+      rw_dma_1k(ok ? X + base + off : zero, buf + sl * G::SLICE + c * 1024);
     }
   };
   const char* M = reinterpret_cast<const char*>(a.mask);
@@ -316,8 +321,9 @@ __global__ __launch_bounds__(NW * 64) void conv_rw8_kernel(const RwP a) {
       const int pix = c * 8 + rr, gy = t.y0 + (pix >> 4), gx = t.x0 + (pix & 15);
       const int chl = sl * 64 + ((lane & 7) ^ rr) * 8, ch = blk * (CT * 16) + chl;      // (from the opaque copy: nothing here is hoisted out of the tile loop)
       const bool ok = t.live && chl < CT * 16 && ch < a.n && gy < a.H && gx < a.W;
-      const char* src = M + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldmask + ch) * 2;
-      rw_dma_1k(ok ? src : zero, mbuf + id * 1024);
+      const long base = ((((long)t.b * a.H + t.y0) * a.W + t.x0) * a.ldmask) * 2;      // (wave-uniform; the lane's part in 24-bit multiply-adds, see piece)
+      const unsigned off = __umul24(__umul24(pix >> 4, a.W) + (pix & 15), a.ldmask * 2) + ch * 2;
+      rw_dma_1k(ok ? M + base + off : zero, mbuf + id * 1024);
     }
   };
   const unsigned mask_base = lds_base + 2 * G::BUF;
