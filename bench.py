@@ -64,12 +64,12 @@ def measured_traffic(B, dtype):
     return None
 
 
-def conv_flops(prog):
-    """Algorithmic FLOPs of the MFMA conv launches (forward + data-gradient) of one step, from the logical layer shapes."""
-    total = 0.0
-    for rec in prog.g.conv_records:
-        total += rec["flops"]
-    return total
+def family_bytes(launches, family, esz):
+    """Algorithmic HBM bytes of the TIMED launches of one family (the per-launch records profile_ops returns -- the same list the family's time
+    and flops come from): every input and output element once, plus the output-shaped operands a launch reads (ReLU mask, residual, the
+    gradient it accumulates into)."""
+    return sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r.get("extra_reads", 0))) * esz
+               for tag, r, _ in launches if tag == family and r and "k" in r and "n" in r)
 
 
 def cpu_baseline(aj, tj, H, W, budget_s=20.0):
@@ -164,7 +164,7 @@ def _timed_steps(trainer, steps, warmup):
 
 def _conv_roofline(prog, peak):
     """MFMA conv launches of one step of `prog` (HIP events per launch): algorithmic FLOPs / their time, and the step's launch-time total."""
-    times = prog.profile_ops(repeats=2)
+    times, launches = prog.profile_ops(repeats=2, detail=True)
     convs = {k: v for k, v in times.items() if k in ("conv_igemm", "conv_bwd", "conv_wgrad", "convt") and v[1] > 0}
     ms, fl = sum(v[1] for v in convs.values()), sum(v[2] for v in convs.values())
     roof = {"bound": "mfma", "kernel": "all MFMA conv launches of the step", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -173,10 +173,8 @@ def _conv_roofline(prog, peak):
     # which roof binds: algorithmic bytes of the forward / data-gradient launches (every input and output element once, plus the output-shaped
     # operands a launch reads: mask, residual, accumulated gradient) against their flops.  Below the ridge (peak / 8 TB/s = 312 flop/B in
     # bf16) the launches are HBM-bound and `bound`, `achieved`, `peak`, `frac` are restated in bytes; the MFMA view stays in `mfma_view`.
-    recs = prog.g.conv_records
-    if recs and "conv_igemm" in times and times["conv_igemm"][1] > 0:
-        esz = 4 if prog.arch.dtype == "f32" else 2
-        by = sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r["extra_reads"])) * esz for r in recs)
+    if "conv_igemm" in times and times["conv_igemm"][1] > 0 and times["conv_igemm"][2] > 0:
+        by = family_bytes(launches, "conv_igemm", 4 if prog.arch.dtype == "f32" else 2)
         fam_fl, fam_ms = times["conv_igemm"][2], times["conv_igemm"][1]
         intensity, ridge = fam_fl / by, 1e3 * peak / PEAK_HBM_GBS
         hbm = {"achieved": by / (fam_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / (fam_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
@@ -317,6 +315,25 @@ def augment_bench(args, device, rank, world):
                           "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None}}))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) through torch.distributed.run on this node and
+    pass their output through -- rank 0 prints the one JSON line with n_gpus = N.  Refuses (non-zero exit) when fewer than N devices are visible
+    instead of measuring fewer (DD_FORCE_DEVICE: the test hook that puts several ranks on one GPU over gloo)."""
+    import socket
+    import subprocess
+    if not os.environ.get("DD_FORCE_DEVICE") and torch.cuda.device_count() < n:
+        raise SystemExit("--gpus %d: only %d device(s) visible; refusing to measure fewer GPUs than asked for" % (n, torch.cuda.device_count()))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,11 +359,15 @@ def main():
         args.batch = 256 if args.mode == "inference" else 128
     if args.dtype is None:
         args.dtype = "f16" if args.mode == "inference" else "bf16"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not os.environ.get("DD_FORCE_DEVICE") and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d: only %d device(s) visible; refusing to measure fewer GPUs than asked for" % (world, torch.cuda.device_count()))
     if os.environ.get("DD_FORCE_DEVICE"):                  # test hook: several ranks on one GPU (with DD_DIST_BACKEND=gloo)
         local_rank = int(os.environ["DD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
@@ -414,6 +435,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
 
+    # ---- the gradient all-reduces of a step on their side stream, and the part the launch stream waited for (every rank runs these steps)
+    coll = trainer.measure_collectives(5) if use_dist else None
+    if use_dist:
+        barrier()
+
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream (outside the timed region)
     roof = None
     if rank == 0:
@@ -430,7 +456,7 @@ def main():
         # algorithmic HBM bytes of the same launches: every input and output element once, plus the output-shaped operands some launches
         # read (the ReLU mask of a dgrad, a residual, the gradient a launch accumulates into)
         esz = 4 if args.dtype == "f32" else 2
-        alg_bytes = sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r["extra_reads"])) * esz for r in trainer.program.g.conv_records)
+        alg_bytes = family_bytes(launches, fam, esz)
         tr = measured_traffic(B, args.dtype)
         roof = {"bound": "mfma", "kernel": "dd_conv_igemm launches <%s>: conv_igemm_ws_kernel, conv_rw_kernel, conv_rw8_kernel (forward + the data gradients the fused "
                           "conv_bwd_kernel does not cover)" % args.dtype, "achieved": achieved, "peak": peak,
@@ -469,6 +495,8 @@ def main():
             # physical devices behind the ranks: == n_gpus except under the DD_FORCE_DEVICE test hook (several ranks sharing one GPU)
             "devices": 1 if os.environ.get("DD_FORCE_DEVICE") else world,
             "collectives": (os.environ.get("DD_DIST_BACKEND", "nccl") if use_dist else None),
+            # per step: time of the bucketed gradient all-reduces on the side stream and how much of it was NOT hidden behind the backward
+            "allreduce": coll,
             "config": {"workload": "BASELINE config 2: U-Net [64,96,128]x4 + 5x5 KernelPrediction + 3-scale MultiScalePrediction, "
                                    "32-channel render-pass stack, %dx%d tiles, full training step (fwd+SMAPE loss+bwd+Adam)" % (H, W),
                        "tiles_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "dp%d" % world,

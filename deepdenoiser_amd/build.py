@@ -38,6 +38,53 @@ NO_SCRATCH = {
 }
 
 
+# Sources with "request now, wait later" inline-asm loads: (request marker, wait marker).  Between the two hipcc believes the destination
+# registers defined although the load may not have landed; the build compiles the file to ISA and refuses it if any instruction in between
+# names one of them (correctness must not depend on the current register allocation).
+ASYNC_LOADS = {"dd_convt.hip": ("dd_accum_request", "dd_accum_wait")}
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    out = set()
+    for m in _VREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check_async_loads(asm, request, wait):
+    """asm: device ISA text (hipcc -S).  Returns the number of request groups checked; raises if an instruction between a request and the
+    following wait touches a register a pending request writes."""
+    pending, groups, fn = {}, 0, "?"
+    for ln, line in enumerate(asm.splitlines(), 1):
+        code = line.split(";", 1)[0].strip()
+        if line and not line[0].isspace() and line.rstrip().endswith(":") and not line.startswith("."):
+            fn = line.rstrip()[:-1]
+            if pending:
+                raise RuntimeError("%s: request at line %d never reached its wait" % (fn, min(pending.values())))
+        if request in line:
+            dst = code.split(None, 1)[1].split(",", 1)[0]
+            if not pending:
+                groups += 1
+            for r in _vregs(dst):
+                pending[r] = ln
+            hit = _vregs(code.split(",", 1)[1]) & set(pending)          # its own address operand must not be a pending destination either
+        elif wait in line:
+            pending = {}
+            continue
+        else:
+            hit = _vregs(code) & set(pending) if (pending and code and not code.startswith(".")) else set()
+        if hit:
+            raise RuntimeError("%s: line %d `%s` touches v%s while its load (line %d) is still in flight"
+                               % (fn, ln, code, sorted(hit), pending[sorted(hit)[0]]))
+    if pending:
+        raise RuntimeError("%s: request never reached its wait" % fn)
+    return groups
+
+
 def source_hash():
     """First 16 hex digits of sha256 over every kernel source and header (name + content, sorted by name)."""
     h = hashlib.sha256()
@@ -100,6 +147,11 @@ def build(force=False, verbose=True, resources=False):
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, src, o, guarded, subprocess.Popen(cmd, stderr=subprocess.PIPE if guarded else None, text=True if guarded else None)))
     failures = []
+    isa = []
+    for cmd, src, o, guarded, p in procs:
+        if src in ASYNC_LOADS:
+            c2 = [hipcc] + [f for f in FLAGS if f != "-fPIC"] + ["-Wno-unused-command-line-argument", "--cuda-device-only", "-S", "-o", "-", os.path.join(CSRC, src)]
+            isa.append((src, subprocess.Popen(c2, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)))
     for cmd, src, o, guarded, p in procs:
         err = p.communicate()[1] if guarded else None
         if p.wait() != 0:
@@ -114,6 +166,18 @@ def build(force=False, verbose=True, resources=False):
             except RuntimeError as e:
                 os.remove(o)
                 failures.append(str(e))
+    for src, p in isa:
+        text = p.communicate()[0]
+        try:
+            if p.returncode != 0:
+                raise RuntimeError("%s: hipcc -S failed" % src)
+            if check_async_loads(text, *ASYNC_LOADS[src]) == 0:
+                raise RuntimeError("%s: no `%s` found in the ISA" % (src, ASYNC_LOADS[src][0]))
+        except RuntimeError as e:
+            o = os.path.join(CSRC, src.replace(".hip", ".o"))
+            if os.path.exists(o):
+                os.remove(o)
+            failures.append(str(e))
     if failures:
         raise RuntimeError("\n".join(failures))
     # dd_version.o carries the source hash: rebuilt whenever the hash it was compiled with differs

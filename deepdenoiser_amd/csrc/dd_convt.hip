@@ -274,7 +274,10 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
     // ACCUM: the gradient already in dx is requested BEFORE the next tile's DMA pieces and waited for with vmcnt(pieces of this wave): loads return
     // in order, so nothing of the DMA has to land first.  (Round 3 loaded it with a plain C++ load behind the pieces: hipcc's own s_waitcnt
     // before its use is vmcnt(0) -- it does not count the inline-asm DMA -- and every tile waited for the whole NEXT tile to arrive, an HBM round
-    // trip per tile.)  The request is inline asm for the same reason; its registers are only touched again behind the explicit wait.
+    // trip per tile.)  The request is inline asm for the same reason; its registers are only touched again behind the explicit wait.  hipcc
+    // believes oldr[] defined right behind the request, so nothing in the language stops it from copying or re-allocating those registers
+    // between the two asm statements (a v_mov there would read them before the load has landed): deepdenoiser_amd/build.py compiles this file
+    // to ISA and REFUSES the build if any instruction between a `dd_accum_request` and the next `dd_accum_wait` names a request register.
     const int jj = cur.j0 + (li & 7);
     const bool ch_ok = c4 < a.cinv && jj < a.W;
     ct_u32x2 oldr[NG];
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
         const int ii = cur.i0 + 2 * g + (li >> 3);
         const bool ok = d_active && ch_ok && ii < a.H;
         const void* op = ok ? static_cast<const void*>(DX + (((long)cur.b * a.H + ii) * a.W + jj) * a.ldo + c4) : static_cast<const void*>(&dd_zero16_v);
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(oldr[g]) : "v"(op) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off ; dd_accum_request" : "=v"(oldr[g]) : "v"(op) : "memory");
       }
     }
     dma_tile(nxt, lds_base + (sel ^ 1) * BUF);
@@ -310,11 +313,11 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
       if (ACCUM) {
         static_assert(NG == 4 || NG == 2, "the wait below names every request register");
         if constexpr (NG == 4) {
-          if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]));
-          else asm volatile("s_waitcnt vmcnt(5)" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]));
+          if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6) ; dd_accum_wait" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]));
+          else asm volatile("s_waitcnt vmcnt(5) ; dd_accum_wait" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]));
         } else {
-          if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(oldr[0]), "+v"(oldr[1]));
-          else asm volatile("s_waitcnt vmcnt(5)" : "+v"(oldr[0]), "+v"(oldr[1]));
+          if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6) ; dd_accum_wait" : "+v"(oldr[0]), "+v"(oldr[1]));
+          else asm volatile("s_waitcnt vmcnt(5) ; dd_accum_wait" : "+v"(oldr[0]), "+v"(oldr[1]));
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) oldv[g] = uint2{oldr[g][0], oldr[g][1]};

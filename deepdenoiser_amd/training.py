@@ -49,6 +49,7 @@ class GradientReducer:
         self.active = world_size > 1 or force
         self._stream = torch.cuda.Stream(device=grads.device) if (self.active and grads.is_cuda) else None
         self._works = []
+        self.timing = None             # measure_collectives(): list of (start, end) events per all-reduce of the current step
 
     def launch(self, lo, hi):
         if not self.active or hi <= lo:
@@ -60,12 +61,21 @@ class GradientReducer:
             ev.record()
             with torch.cuda.stream(self._stream):
                 self._stream.wait_event(ev)
+                if self.timing is not None:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing is not None:
+                    t1.record()
+                    self.timing.append((t0, t1))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
         if self._stream is not None:
+            if self.timing is not None:       # when the launch stream gets here (everything it had to do beside the collectives is queued before)
+                self._ready = torch.cuda.Event(enable_timing=True)
+                self._ready.record()
             torch.cuda.current_stream().wait_stream(self._stream)
         for w in self._works:
             w.wait()
@@ -149,3 +159,24 @@ class Trainer:
         self.reducer.wait()
         prog.adam(grad_scale=self.reducer.grad_scale)
         return prog.loss_buf
+
+    def measure_collectives(self, steps=5):
+        """Per-step time of the gradient all-reduces on the side stream and the part of it the launch stream had to wait for (HIP events; run
+        OUTSIDE a timed region, by every rank).  exposed = (end of the last all-reduce) - (the launch stream reaching the join), clipped at 0:
+        what a scaling curve below the ideal loses to communication as opposed to launch overhead or input feeding.  None without a side
+        stream (one rank without forced collectives, CPU / gloo work handles)."""
+        r = self.reducer
+        if r._stream is None:
+            return None
+        tot, exposed, n = 0.0, 0.0, 0
+        for _ in range(steps):
+            r.timing = []
+            self.step()
+            torch.cuda.synchronize()
+            tot += sum(a.elapsed_time(b) for a, b in r.timing)
+            n = len(r.timing)
+            if r.timing:
+                exposed += max(0.0, r._ready.elapsed_time(r.timing[-1][1]))
+        r.timing = None
+        return {"allreduce_ms_per_step": tot / steps, "exposed_ms_per_step": exposed / steps, "allreduces_per_step": n,
+                "bytes_per_step": int(self.arch.params.grads.numel() * self.arch.params.grads.element_size())}

@@ -108,3 +108,36 @@ def test_bench_runs_its_distributed_path_over_rccl_with_one_rank():
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["devices"] == 1 and rec["collectives"] == "nccl"
     assert rec["steps"] == 4 and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+    assert rec["allreduce"]["allreduces_per_step"] >= 1 and rec["allreduce"]["allreduce_ms_per_step"] > 0 and rec["allreduce"]["exposed_ms_per_step"] >= 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's 1-GPU command) starts two ranks itself and reports n_gpus 2.
+    On the one-GPU box both ranks share device 0 over gloo (DD_FORCE_DEVICE / DD_DIST_BACKEND: test hooks); on a node the same command runs
+    one rank per GPU over RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, DD_FORCE_DEVICE="0", DD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "8", "--no-extras", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                      # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["devices"] == 1 and rec["collectives"] == "gloo"
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
+    assert rec["steps"] == 3 and rec["value"] > 0
+    assert rec["allreduce"] is not None and rec["allreduce"]["allreduces_per_step"] >= 2
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus N with fewer than N devices must fail instead of silently measuring fewer."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "DD_FORCE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "refusing" in (p.stdout + p.stderr)
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
