@@ -451,6 +451,10 @@ def main():
                 json.dump([{"family": tag, "us": round(us, 2), **({k: v for k, v in info.items()} if info else {})} for tag, info, us in launches], fh, indent=0)
         fam = "conv_igemm"
         n, ms, flops = times[fam]
+        # the family's work is the sum over the launches that were timed; the engine's own records must say the same (round 4: they did not --
+        # the layer-wise compose net recorded launches its fused replacement never runs)
+        rec_flops = sum(r["flops"] for r in trainer.program.g.conv_records)
+        assert abs(rec_flops - flops) <= 1e-9 * flops, ("conv_igemm records %.1f GFLOP != timed launches %.1f GFLOP" % (rec_flops / 1e9, flops / 1e9))
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
         # algorithmic HBM bytes of the same launches: every input and output element once, plus the output-shaped operands some launches

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       asm volatile("" : "+v"(rr), "+v"(xl));
       if (k < QPC) {
         const int c = wr * QPC + k, row = c >> 1, h = c & 1;
+#ifdef CBW_EXP_NO_DMA
+        const bool ok = false;      // (knock-out build: every piece comes from the zero page)
+#else
         const bool ok = o.live && x_ok && o.y0 + row < a.H && o.x0 + h * 8 + rr < a.W;
+#endif
         bw_dma_1k(ok ? o.q + (row * x_row + h * 8 * a.ldx * 2 + xl) : zero, buf + BW_P_BYTES + c * 1024);
       } else {
         const int c = (k - QPC) * 4 + wr;
@@ -156,7 +160,11 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
           const int pix = c * 8 + rr;
           const int py = (pix * 3641) >> 16, px = pix - py * PW;          // pix / 18 for pix < 400
           const int gy = o.y0 - 1 + py, gx = o.x0 - 1 + px;
+#ifdef CBW_EXP_NO_DMA
+          const bool ok = false;
+#else
           const bool ok = o.live && d_ok && pix < PW * PW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+#endif
           bw_dma_1k(ok ? o.p + (py * dy_row + px * dy_pix + dy_lane) : zero, buf + c * 1024);
         }
       }

@@ -20,8 +20,10 @@ __global__ __launch_bounds__(512) void probe(uint32_t* out, long long* cycles, i
     const int li = lane & 15, q = lane >> 4;
     addr = base + li * 128 + ((q ^ (li & 7)) << 4);
   } else {                    // transposing reads: lane (t16, gq): pixel gq*8 + (t16 >> 2), 8 bytes at slot pair (sub >> 1), half sub & 1
-    const int t16 = lane & 15, gq = lane >> 4, sub = t16 & 3, pl = gq * 8 + (t16 >> 2);
-    const int key = KEY == 0 ? (pl & 7) : ((pl & 3) << 1);
+    // KEY 0 / 1: the layout of rounds 2-4 (a 32-lane service group holds pixels {0..3, 8..11}: p and p + 8 share p & 7 -> the same banks);
+    // KEY 2: a 32-lane group holds 8 CONSECUTIVE pixels (round 5)
+    const int t16 = lane & 15, gq = lane >> 4, sub = t16 & 3, pl = KEY == 2 ? (gq >> 1) * 16 + (gq & 1) * 4 + (t16 >> 2) : gq * 8 + (t16 >> 2);
+    const int key = KEY == 1 ? ((pl & 3) << 1) : (pl & 7);
     addr = base + pl * 128 + (((sub >> 1) ^ key) << 4) + (sub & 1) * 8;
   }
   uint32_t accx = 0;
@@ -72,5 +74,7 @@ int main() {
   run<1, 1>("ds_read_b64 tr-pattern (key 2(p&3))", 8);
   run<2, 0>("ds_read_b64_tr_b16 (key p&7)", 8);
   run<2, 1>("ds_read_b64_tr_b16 (key 2(p&3))", 8);
+  run<1, 2>("ds_read_b64 8 consecutive px / 32 lanes", 8);
+  run<2, 2>("ds_read_b64_tr_b16 8 consecutive px", 8);
   return 0;
 }

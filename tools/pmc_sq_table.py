@@ -21,7 +21,7 @@ def load(d):
 
 a, b = load(sys.argv[1]), load(sys.argv[2])
 pats = sys.argv[3:] or ["conv_rw", "conv_bwd", "compose", "conv_igemm_ws", "head_", "wgrad"]
-print("%-58s %5s %9s | %6s %6s %6s %6s | %7s %7s %7s | %8s %8s" % ("kernel", "calls", "wave-cyc", "parked", "stall", "active", "stlLDS", "VALU/w", "SALU/w", "LDS/w", "MFMAbusy", "LDSconfl"))
+print("%-58s %5s %9s | %6s %6s %6s %6s | %7s %7s %7s | %8s %8s" % ("kernel", "calls", "wave-cyc", "parked", "stall", "active", "stlLDS", "VALU/w", "SALU/w", "LDS/w", "MFMAbusy", "LDSconfl") + " %8s" % "LDSbusy")
 for name in sorted(a):
     if not any(p in name for p in pats):
         continue
@@ -30,11 +30,12 @@ for name in sorted(a):
     wc = m(A, "SQ_WAVE_CYCLES")
     waves = m(B, "SQ_WAVES")
     busy = m(B, "SQ_BUSY_CU_CYCLES")
-    print("%-58s %5d %9.3g | %5.1f%% %5.1f%% %5.1f%% %5.1f%% | %7.0f %7.0f %7.0f | %7.1f%% %7.1f%%" % (
+    print("%-58s %5d %9.3g | %5.1f%% %5.1f%% %5.1f%% %5.1f%% | %7.0f %7.0f %7.0f | %7.1f%% %7.1f%% %7.1f%%" % (
         name[:58], len(A["SQ_WAVE_CYCLES"]), wc,
         100 * m(A, "SQ_WAIT_ANY") / wc, 100 * m(A, "SQ_WAIT_INST_ANY") / wc, 100 * m(A, "SQ_ACTIVE_INST_ANY") / wc, 100 * m(A, "SQ_WAIT_INST_LDS") / wc,
         m(B, "SQ_INSTS_VALU") / waves, m(B, "SQ_INSTS_SALU") / waves, m(B, "SQ_INSTS_LDS") / waves,
         100 * m(B, "SQ_VALU_MFMA_BUSY_CYCLES") / (4 * busy) if busy == busy else float("nan"),
-        100 * m(B, "SQ_LDS_BANK_CONFLICT") / m(B, "SQ_LDS_IDX_ACTIVE") if m(B, "SQ_LDS_IDX_ACTIVE") else float("nan")))
+        100 * m(B, "SQ_LDS_BANK_CONFLICT") / m(B, "SQ_LDS_IDX_ACTIVE") if m(B, "SQ_LDS_IDX_ACTIVE") else float("nan"),
+        100 * m(B, "SQ_LDS_IDX_ACTIVE") / busy if busy == busy else float("nan")))
 print("columns: parked = SQ_WAIT_ANY, stall = SQ_WAIT_INST_ANY, active = SQ_ACTIVE_INST_ANY, stlLDS = SQ_WAIT_INST_LDS, each / SQ_WAVE_CYCLES; per-wave instruction counts;")
-print("         MFMAbusy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); LDSconfl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE")
+print("         MFMAbusy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); LDSconfl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; LDSbusy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES (LDS-array cycles per CU cycle)")
