@@ -912,7 +912,9 @@ extern "C" int dd_compose_net_fwd(const dd_compose_args* a, dd_stream stream) {
   {
     // round 4: the row-streaming kernel (csrc/dd_compose_stream.hip) is the forward; DD_COMPOSE_STREAM=0 keeps the 16x16-tile kernel below
     static const bool stream_fwd = !(getenv("DD_COMPOSE_STREAM") && getenv("DD_COMPOSE_STREAM")[0] == '0');
-    if (stream_fwd) return dd_compose_stream_fwd_launch(a, reinterpret_cast<hipStream_t>(stream));
+    // (the streaming kernel has 32-bit pixel offsets: launches of 2^25 pixels or more fall through to the tile kernel below, whose offsets are
+    //  64-bit -- the same condition dd_compose_net_bwd applies, so the two directions agree)
+    if (stream_fwd && (long)a->N * a->H * a->W < (1l << 31) / 64) return dd_compose_stream_fwd_launch(a, reinterpret_cast<hipStream_t>(stream));
   }
   ComposeP p;
   p.small = a->small; p.fine = a->fine; p.out = a->out;

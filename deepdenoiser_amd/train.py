@@ -61,9 +61,14 @@ class TileStream:
     as validation reads them); `threads` decoder threads each own a file at a time and hand decoded examples to the batcher IN FILE ORDER
     (the shuffled order), so the sequence of examples does not depend on thread timing."""
 
-    def __init__(self, directory, mode, arch, batch, tile, spp, index_tuples, rank=0, world=1, rng=None, threads=4, prefetch=5, pinned=True):
+    def __init__(self, directory, mode, arch, batch, tile, spp, index_tuples, rank=0, world=1, rng=None, threads=4, prefetch=5, pinned=True,
+                 pad_last=False):
+        """pad_last (validation): the examples left over after the last whole round of `world` mini-batches are evaluated too -- the round is
+        filled up by repeating examples from the start of the epoch (`padded` counts them; the reference's dataset.batch() evaluates the
+        remainder as a smaller batch, a static launch program cannot).  Without it they are dropped and counted in `dropped`."""
         self.arch, self.batch, self.tile, self.spp, self.tuples = arch, batch, tile, spp, index_tuples
         self.rank, self.world, self.rng, self.prefetch, self.pinned = rank, world, rng, prefetch, pinned
+        self.pad_last, self.padded, self.dropped, self._const = pad_last, 0, 0, {}
         self.passes = {f.name: f.number_of_channels for f in arch.feature_predictions + arch.auxiliary_features if f.load_data}
         self.targets = [f.name for f in arch.feature_predictions if f.load_data and f.is_target]
         self.required = sorted({i for t in index_tuples for i in t})
@@ -90,11 +95,15 @@ class TileStream:
 
         def worker():
             while True:
+                # the look-ahead permit comes BEFORE the index, both under one lock: a permit holder then always owns the lowest outstanding
+                # index (taken the other way round the other workers could park 2 x threads later files, take every permit, and leave the
+                # worker holding the index the consumer waits for without one: ADVICE r4)
                 with lock:
+                    ahead.acquire()
                     i = next(nxt, None)
                 if i is None:
+                    ahead.release()
                     return
-                ahead.acquire()
                 try:
                     slots[i].put(self._decode_file(self.files[i]))
                 except BaseException as e:                               # surfaces in the consumer
@@ -129,9 +138,8 @@ class TileStream:
         feats, labels = {}, {}
         B, tile = self.batch, self.tile
 
-        def host(shape):
-            t = torch.empty(shape, dtype=torch.float32)
-            return t.pin_memory() if self.pinned else t
+        def host(shape):      # (allocated pinned: empty(...).pin_memory() allocates pageable memory and copies its garbage into a second buffer)
+            return torch.empty(shape, dtype=torch.float32, pin_memory=bool(self.pinned and torch.cuda.is_available()))
         for k, ch in self.passes.items():
             t = host((B, tile, tile, ch))
             np.stack([s[k] for s, _ in group], out=t.numpy())
@@ -143,9 +151,12 @@ class TileStream:
         for f in self.arch.feature_predictions + self.arch.auxiliary_features:      # generated passes (Training.py:531-538)
             if not f.load_data:
                 value = 1.0 if f.feature_prediction_type == "COLOR" else 0.5
-                feats[Naming.source_feature_name(f.name, index=0)] = torch.full((B, tile, tile, f.number_of_channels), value)
+                key = (f.number_of_channels, value)
+                if key not in self._const:      # constant passes: one (pinned) tensor for the whole stream, not one per mini-batch
+                    self._const[key] = host((B, tile, tile, f.number_of_channels)).fill_(value)
+                feats[Naming.source_feature_name(f.name, index=0)] = self._const[key]
                 if f.is_target:
-                    labels[Naming.target_feature_name(f.name)] = torch.full((B, tile, tile, f.number_of_channels), value)
+                    labels[Naming.target_feature_name(f.name)] = self._const[key]
         return feats, labels
 
     def __iter__(self):
@@ -155,9 +166,11 @@ class TileStream:
 
         def producer():
             try:
-                group, buf = [], []
-                for ex in self._shuffled():
-                    self.decoded += 1
+                group, buf, head = [], [], []
+                need = self.batch * self.world
+
+                def feed(ex):
+                    nonlocal group, buf
                     buf.append(ex)
                     if len(buf) == self.batch:
                         group.append(buf)
@@ -165,6 +178,18 @@ class TileStream:
                         if len(group) == self.world:                     # only whole rounds of `world` mini-batches: every rank gets one
                             ready.put(self._stack(group[self.rank]))
                             group = []
+                for ex in self._shuffled():
+                    self.decoded += 1
+                    if self.pad_last and len(head) < need:
+                        head.append(ex)
+                    feed(ex)
+                left = len(group) * self.batch + len(buf)
+                if left and self.pad_last and head:
+                    for k in range(need - left):                         # fill the last round with examples from the start of the epoch
+                        feed(head[k % len(head)])
+                    self.padded = need - left
+                else:
+                    self.dropped = left
                 ready.put(END)
             except BaseException as e:
                 ready.put(e)
@@ -210,7 +235,7 @@ def run_validation(trainer, arch, tj, base, B, rank, world, threads):
         if st["tiles_height_width"] != trainer.program.H:
             print("validation set %s: tiles of %d pixels, the program was built for %d -- skipped" % (name, st["tiles_height_width"], trainer.program.H))
             continue
-        stream = TileStream(vdir, "validation", arch, B, st["tiles_height_width"], spp, tuples, rank, world, rng=None, threads=threads)
+        stream = TileStream(vdir, "validation", arch, B, st["tiles_height_width"], spp, tuples, rank, world, rng=None, threads=threads, pad_last=True)
         total = torch.zeros(2, dtype=torch.float64, device=arch.device)
         for feats, labels in stream:
             trainer.program.set_inputs({k: v.to(arch.device) for k, v in feats.items()}, {k: v.to(arch.device) for k, v in labels.items()})
@@ -222,6 +247,8 @@ def run_validation(trainer, arch, tj, base, B, rank, world, threads):
             dist.all_reduce(total)
         if float(total[1]) > 0:
             results.append((os.path.splitext(name)[0], float(total[0] / total[1]), int(total[1])))
+            if stream.padded and rank == 0:
+                print("validation set %s: the last round was filled up with %d repeated example(s) (%d decoded)" % (name, stream.padded, stream.decoded))
     return results
 
 

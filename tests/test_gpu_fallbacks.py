@@ -10,13 +10,22 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CASES = {
+CASES = {   # name: (environment of the child, -k expression[, test file (default tests/test_gpu_ops.py)])
     # round-1 library: no wave-specialised / register-weight / LDS-DMA / GEMM-tile kernels
     "round1_kernels": ({"DD_CONV_WS": "0", "DD_CONV_RW": "0", "DD_WGRAD_DMA": "0", "DD_CONV_PW": "0"},
                        "test_conv_fwd_bwd or test_conv_non_square_batches or test_conv_grad_accumulation"),
     # the older members of the register-weight family, the plain tile walk, the mid-sized 1x1 weight gradient on the GEMM kernel
     "older_variants": ({"DD_CONV_RW8": "0", "DD_CONV_RW12": "0", "DD_CONV_XCD": "0", "DD_WGRAD_PW_MID": "1"},
                        "test_conv3x3_random_shapes_round2_kernels or test_conv_over_skip_concat or (test_conv_fwd_bwd and bf16)"),
+    # round 5 (dead-path coverage): the kernels the round-4 defaults superseded stay reachable through switches and odd shapes, so they
+    # stay gated -- the 6 + 2 wave conv_rw_kernel with its own mask / residual loads (the all-wave AUX forms off), the generic max-pool backward,
+    "masked_6plus2_and_generic_unpool": ({"DD_CONV_RW12_MASK": "0", "DD_CONV_RW8_MASK": "0", "DD_MAXPOOL_GENERIC": "1"},
+                                         "test_conv_fwd_bwd or test_conv_over_skip_concat or test_conv_grad_accumulation or test_maxpool"),
+    # ... and the 16 x 16-tile compose kernels of round 2 / 3 (csrc/dd_compose.hip) in place of the row-streaming ones, forward and backward
+    "tile_compose_kernels": ({"DD_COMPOSE_STREAM": "0", "DD_COMPOSE_STREAM_BWD": "0"},
+                             "test_fused_compose_net_matches_the_layerwise_path", "test_gpu_round2.py"),
+    "tile_compose_kernels_bit_faithful": ({"DD_COMPOSE_STREAM": "0", "DD_COMPOSE_STREAM_BWD": "0"},
+                                          "test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful", "test_gpu_round3.py"),
 }
 
 
@@ -26,11 +35,12 @@ def test_op_parity_with_library_paths_switched_off(name):
     import torch
     if not torch.cuda.is_available():      # the child would skip every test and report none passed (plain `pytest tests` on a box without a GPU)
         pytest.skip("no GPU")
-    env_extra, expr = CASES[name]
+    env_extra, expr = CASES[name][:2]
+    test_file = CASES[name][2] if len(CASES[name]) > 2 else "test_gpu_ops.py"
     env = dict(os.environ, **env_extra)
     env.pop("DD_PARITY_REPORT", None)
     env["DD_PARITY_FILE"] = "parity_errors_%s.txt" % name      # the child's comparisons, beside the parent's gpurun_out/parity_errors.txt
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q", "-k", expr,
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-m", "gpu", "-x", "-q", "-k", expr,
                         "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     tail = "\n".join(p.stdout.strip().splitlines()[-15:])
     assert p.returncode == 0, "%s: child pytest failed\n%s\n%s" % (name, tail, p.stderr[-2000:])

@@ -761,3 +761,84 @@ def test_conv_pair_inference_forward(eng, dtype, cin, cmid, cout, H, W, B, relu2
     check("y", read(y), want, 2 * ROUND[dtype])      # (a stored intermediate value on the other side of a rounding boundary moves an output by one more rounding)
     untouched = float((wide.buf[..., :8].float() - 3.0).abs().max()) == 0.0 and float((wide.buf[..., 8 + cout:].float() - 3.0).abs().max()) == 0.0
     assert untouched, "channels next to the output range were written"
+
+
+# ---------------------------------------------------------------------------------------------------------------- compose net backward, op level
+# dd_compose_net_bwd on the row-streaming path (caller scratch; csrc/dd_compose_stream_bwd.hip: the data launch + the weight-gradient launch) fed
+# with the activations of the STORAGE-EMULATING oracle itself: no forward of ours in between, so no rounding flip of a stored activation can
+# decorrelate the comparison -- what is left is the fp32 summation order of the MFMAs and the one rounding per parked gradient the emulation
+# makes too (the model-level gates on reused_compose_scales/* are conditioned; this one is not).  Shapes: one strip, W > 64 (two
+# weight-gradient strips), W > 128 (three forward / data strips of 96 with their 4-column halo), ragged rows and columns, several bands.
+COMPOSE_BWD_SHAPES = [(2, 16, 32), (1, 20, 72), (2, 36, 136), (1, 18, 200), (3, 64, 64)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", COMPOSE_BWD_SHAPES)
+def test_compose_net_backward_streaming_op_level(dtype, shape):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from deepdenoiser_amd import _lib as L
+    from oracle import model as OM
+    lib = L.load()
+    N, H, W = shape
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(11 + N + H + W)
+    vs = OM.VarStore(torch.float64, seed=5, storage=dtype)
+    vs.enter_scope("s")
+    recorded = []
+    conv2d = vs.conv2d
+
+    def recording(*a, **k):
+        y = conv2d(*a, **k)
+        recorded.append(y)
+        return y
+    vs.conv2d = recording
+    small = (torch.randn(N, H // 2, W // 2, 3, generator=g, dtype=torch.float64) * 0.7).float().double().requires_grad_(True)
+    fine = (torch.randn(N, H, W, 3, generator=g, dtype=torch.float64) * 0.7).float().double().requires_grad_(True)
+    gout = torch.randn(N, H, W, 3, generator=g, dtype=torch.float64).float().double()
+    out = OM.compose_scales(vs, "s", small, fine)
+    for name, v in vs.vars.items():      # glorot kernels, and biases away from zero (as after some training)
+        if name.endswith("/bias"):
+            with torch.no_grad():
+                v.copy_(torch.randn(v.shape, generator=g, dtype=torch.float64) * 0.1)
+    recorded.clear()
+    vs.enter_scope("s")
+    out = OM.compose_scales(vs, "s", small, fine)
+    names = list(vs.vars)
+    grads = torch.autograd.grad((out * gout).sum(), [small, fine] + [vs.vars[n] for n in names])
+    a1, r1, a2, r3, a3, wl = [t.detach() for t in recorded]
+    acts = [a1, torch.relu(r1), a2, torch.relu(r3), a3]
+    dev = "cuda"
+    keep = [t.to(dev, tdt).contiguous() for t in acts] + [wl.to(dev, tdt).contiguous()]
+    w32 = {n: vs.vars[n].detach().float().to(dev).contiguous() for n in names}
+    dws = {n: torch.zeros_like(w32[n]) for n in names}
+    d_small = torch.zeros(N, H // 2, W // 2, 3, device=dev)
+    d_fine = torch.zeros(N, H, W, 3, device=dev)
+    sm, fi, go = small.detach().float().to(dev), fine.detach().float().to(dev), gout.float().to(dev)
+    cb = L.ComposeBwdArgs()
+    C.memset(C.byref(cb), 0, C.sizeof(cb))
+    cb.small, cb.ld_small, cb.fine, cb.ld_fine, cb.dout, cb.ld_dout = sm.data_ptr(), 3, fi.data_ptr(), 3, go.data_ptr(), 3
+    for i in range(5):
+        cb.act[i], cb.ld_act[i] = keep[i].data_ptr(), 24
+    cb.wl, cb.ld_wl = keep[5].data_ptr(), 1
+    layer = ["s/conv2d"] + ["s/conv2d_%d" % i for i in range(1, 6)]
+    cb.w_in, cb.dw_in, cb.db_in = w32[layer[0] + "/kernel"].data_ptr(), dws[layer[0] + "/kernel"].data_ptr(), dws[layer[0] + "/bias"].data_ptr()
+    for i in range(4):
+        cb.w_res[i], cb.dw_res[i], cb.db_res[i] = (w32[layer[1 + i] + "/kernel"].data_ptr(), dws[layer[1 + i] + "/kernel"].data_ptr(),
+                                                   dws[layer[1 + i] + "/bias"].data_ptr())
+    cb.w_out, cb.dw_out, cb.db_out = w32[layer[5] + "/kernel"].data_ptr(), dws[layer[5] + "/kernel"].data_ptr(), dws[layer[5] + "/bias"].data_ptr()
+    cb.d_small, cb.ld_dsmall, cb.accumulate_small, cb.d_fine, cb.ld_dfine = d_small.data_ptr(), 3, 0, d_fine.data_ptr(), 3
+    cb.N, cb.H, cb.W, cb.dtype = N, H, W, {"bf16": L.DD_BF16, "f16": L.DD_F16}[dtype]
+    need = int(lib.dd_compose_bwd_scratch_bytes(N, H, W))
+    scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    cb.scratch, cb.scratch_bytes = scratch.data_ptr(), need
+    L.check(lib.dd_compose_net_bwd(C.byref(cb), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    # fp32 outputs of a chain whose parked gradients are rounded once each (as the emulation rounds them): a flipped rounding of one parked
+    # element moves a 24 x 216 gradient by ~1e-5 of its norm; a dropped halo column, tap or strip seam shows at >= 1e-3
+    tol = 2e-4
+    check("compose bwd d_small", d_small.double().cpu(), grads[0], tol)
+    check("compose bwd d_fine", d_fine.double().cpu(), grads[1], tol)
+    for n, gr in zip(names, grads[2:]):
+        check("compose bwd d %s" % n, dws[n].double().cpu(), gr, tol)

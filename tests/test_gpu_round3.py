@@ -39,12 +39,17 @@ def _emulated_step(aj, tj, dtype, feats, labels, loss_scale):
     return oracle, [{k: v.detach() for k, v in d.items()} for d in preds], float(loss), grads
 
 
+CONDITIONED = [("reused_compose_scales/", "/bias")]      # (name prefix, suffix): near-zero-sum bias gradients, see _compare
+
+
 def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate, fwd_median_gate=None, tight=None, conditioned=False):
     """tight = (name prefixes, gate): parameters whose gradient must match at summation-order level (see the bit-faithful test below).
-    conditioned: a tensor's error is taken relative to max(|g|, |g - g_plain|), g_plain = the plain f64 oracle's gradient: where storage rounding
-    ALONE moves a gradient by more than its own norm (a bias gradient of the compose net that sums to nearly zero: 0.46 of its norm in round 3,
-    19 x in round 4 for the same kernels) the relative error of any half-precision run is unbounded, and the distance the emulation itself travels
-    is the scale that means something."""
+    conditioned: for the tensors on the allow-list CONDITIONED below (the compose net's bias gradients, sums over every pixel that come out near
+    zero) the error is taken relative to max(|g|, |g - g_plain|), g_plain = the plain f64 oracle's gradient: where storage rounding ALONE moves a
+    gradient by more than its own norm (0.46 of its norm in round 3, 19 x in round 4 for the same kernels) the relative error of any half-precision
+    run is unbounded, and the distance the emulation itself travels is the scale that means something.  Every other tensor keeps the plain
+    relative error; the streaming compose backward's own gradients are gated without conditioning, op by op, in
+    tests/test_gpu_ops.py::test_compose_net_backward_streaming_op_level."""
     from deepdenoiser_amd.architecture import Architecture
     plain = OracleArchitecture(aj, dtype=torch.float64, seed=2)
     feats, labels = _inputs(plain, B, H, W)
@@ -75,7 +80,7 @@ def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate
             assert float(got.abs().max()) < 1e-6, p.name
             continue
         e = rel_l2(got, go)
-        if gp is not None:
+        if gp is not None and any(p.name.startswith(pre) and p.name.endswith(suf) for pre, suf in CONDITIONED):
             e = float((got - go).norm() / max(float(go.norm()), float((go - gp).norm())))
         errs.append((e, p.name))
         if tight is not None and any(p.name.startswith(pre) for pre in tight[0]):

@@ -71,3 +71,41 @@ def test_evaluation_jsons_lists_the_validation_sets(tmp_path):
     for name in ("validation_4.json", "validation_16.json", "validation_statistics.json", "training_4.json", "validation.txt"):
         (tmp_path / name).write_text("{}")
     assert evaluation_jsons(str(tmp_path), "validation") == ["validation_16.json", "validation_4.json"]
+
+
+def test_validation_stream_pads_its_last_round_and_training_counts_what_it_drops(tmp_path):
+    """35 examples, batch 4, two ranks: training drops the 3 left after 4 rounds and says so; a validation stream (pad_last) fills a fifth round
+    with repeats from the start of the epoch, so every example is evaluated."""
+    aj = configs.architecture(filters=(16, 24), convs=1, flag_mode="NONE")
+    arch = Architecture(aj, device="cpu")
+    base = str(tmp_path / "data")
+    first, n = _dataset(base, arch, n_files=5, per_file=7)
+    B, world = 4, 2
+    tr = TileStream(os.path.join(base, "training"), "training", arch, B, T, SPP, [[0]], 0, world, rng=None, threads=2, pinned=False)
+    assert len(_ids(tr, first)) == 4 and tr.dropped == 3 and tr.padded == 0
+    seen = []
+    for rank in range(world):
+        va = TileStream(os.path.join(base, "training"), "training", arch, B, T, SPP, [[0]], rank, world, rng=None, threads=3, pinned=False, pad_last=True)
+        ids = _ids(va, first)
+        assert len(ids) == 5 and va.padded == 5 and va.dropped == 0
+        seen += [i for b in ids for i in b]
+    assert set(seen) == set(range(n)) and len(seen) == 40
+    # a set smaller than one round still yields one (it yielded nothing before)
+    small = str(tmp_path / "small")
+    first, n = _dataset(small, arch, n_files=1, per_file=3)
+    va = TileStream(os.path.join(small, "training"), "training", arch, B, T, SPP, [[0]], 1, world, rng=None, threads=1, pinned=False, pad_last=True)
+    ids = _ids(va, first)
+    assert len(ids) == 1 and va.padded == 5 and set(ids[0]) <= set(range(n))
+
+
+def test_decoder_threads_cannot_starve_the_file_the_consumer_waits_for(tmp_path):
+    """More files than look-ahead permits and one decoder thread per permit pair: every run must terminate and keep file order (the permit is taken
+    before the file index, under one lock)."""
+    aj = configs.architecture(filters=(16, 24), convs=1, flag_mode="NONE")
+    arch = Architecture(aj, device="cpu")
+    base = str(tmp_path / "data")
+    first, n = _dataset(base, arch, n_files=24, per_file=2)
+    for threads in (1, 2, 8):
+        st = TileStream(os.path.join(base, "training"), "training", arch, 4, T, SPP, [[0]], 0, 1, rng=None, threads=threads, pinned=False)
+        flat = [i for b in _ids(st, first) for i in b]
+        assert flat == list(range(n))
