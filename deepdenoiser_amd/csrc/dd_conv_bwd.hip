@@ -22,8 +22,6 @@
 //     one set of fp32 atomics per workgroup at the end.
 // A SIMD hosts one wave of each role: 576 MFMAs per tile and SIMD.  Channels: C_out <= 64 (one 128-byte LDS row per pixel), C_in in blocks of
 // 64 (one workgroup column per block; dy is re-read per block).
-#include <stdlib.h>
-
 #include "dd_common.h"
 
 #ifndef CBW_DF_RING
@@ -34,7 +32,6 @@
 #endif
 namespace {
 
-constexpr int BW_MAX_PAIRS = 32;
 struct BwdP {
   const void* dy; const void* x; const void* wd; void* dx; float* dw; float* db;
   int lddy, ldx, lddx;
@@ -44,10 +41,6 @@ struct BwdP {
   int nblk, nblk_co, ksplit;       // 64-channel blocks of C_in / of C_out (> 1 only without a data gradient); workgroups per block pair
   int co_base;                     // with a data gradient and C_out > 64: this LAUNCH covers output channels [co_base, co_base + 64) (host loop)
   int use_mask, accumulate;
-  // Round 5: workgroups per (input block, output block) pair in proportion to the pair's work.  wg_start[p] .. wg_start[p + 1] are pair p's
-  // workgroups (npairs > 0; every count a multiple of 8 so that a pair's workgroups still rotate over the XCDs from 0); npairs == 0: ksplit each.
-  int npairs;
-  unsigned short wg_start[BW_MAX_PAIRS + 1];
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
@@ -103,15 +96,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
   static_assert(sizeof(T) == 2, "fused conv backward: bf16 / fp16 storage");
   constexpr int PW = BW_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int pair, ks, ksplit;
-  if (a.npairs > 0) {      // uneven split (weights-only launches over several channel-block pairs): wave-uniform scan of <= 32 boundaries
-    pair = 0;
-    while (pair + 1 < a.npairs && (int)blockIdx.x >= a.wg_start[pair + 1]) ++pair;
-    ks = blockIdx.x - a.wg_start[pair];
-    ksplit = a.wg_start[pair + 1] - a.wg_start[pair];
-  } else {
-    pair = blockIdx.x / a.ksplit; ks = blockIdx.x - pair * a.ksplit; ksplit = a.ksplit;
-  }
+  const int pair = blockIdx.x / a.ksplit, ks = blockIdx.x - pair * a.ksplit;
   const int cb = pair % a.nblk, ob = pair / a.nblk + (a.co_base >> 6);      // input- / output-channel block of this workgroup column
   const int wr = wave & 3;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -123,9 +108,9 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 #ifdef CBW_EXP_NO_XCD
   const int xcd_n = 1;
 #else
-  const int xcd_n = (ksplit & 7) == 0 ? 8 : 1;
+  const int xcd_n = (a.ksplit & 7) == 0 ? 8 : 1;
 #endif
-  const int per_xcd = ksplit / xcd_n;
+  const int per_xcd = a.ksplit / xcd_n;
   const int tile0 = (ks % xcd_n) * per_xcd + ks / xcd_n;      // first tile; then + ksplit per iteration
 
   if (wave < 4) {
@@ -220,10 +205,10 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
     const long row_stride = (long)a.W * a.lddx;
 
     int sel = 0;
-    for (int tile = tile0; tile < total_tiles; tile += ksplit, sel ^= 1) {
+    for (int tile = tile0; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
       __syncthreads();                      // ... and everyone's; buffer sel^1 is free
-      const Origin on = origin(tile + ksplit);
+      const Origin on = origin(tile + a.ksplit);
       if (!active) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) piece(k, on, sel ^ 1);
@@ -338,7 +323,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
     };
 
     int sel = 0;
-    for (int tile = tile0; tile < total_tiles; tile += ksplit, sel ^= 1) {
+    for (int tile = tile0; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
       __syncthreads();      // the data-gradient waves' DMA of `tile` has landed (they wait for it before this barrier); buffer sel^1 is free
       if (!active) continue;
       // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each; the dy fragment of step n+1 and (during taps 4..7) the x fragments of the next
@@ -423,7 +408,7 @@ template <typename T, bool MASK, bool ACCUM>
 int launch_bwd_flags(const BwdP& p, hipStream_t stream) {
   const size_t lds = 2 * (size_t)BW_BUF;
   dd_allow_max_lds(reinterpret_cast<const void*>(conv_bwd_kernel<T, MASK, ACCUM>));
-  const long blocks = p.npairs > 0 ? (long)p.wg_start[p.npairs] : (long)p.nblk * p.nblk_co * p.ksplit;
+  const long blocks = (long)p.nblk * p.nblk_co * p.ksplit;
   hipLaunchKernelGGL((conv_bwd_kernel<T, MASK, ACCUM>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -467,36 +452,6 @@ extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   if (ksplit > total_tiles) ksplit = total_tiles;
   p.ksplit = (int)ksplit;
   p.use_mask = a->use_mask;
-  // Weights-only launches over several channel-block pairs (C_out > 64): a pair with a 32-channel input block has half the MFMAs per tile of a
-  // 64-channel one but got the same number of workgroups, and the launch lasted as long as its heaviest pairs (96 -> 96: 16 + 8 + 8 + 4 units of
-  // work over 4 x 64 workgroups).  Measured per tile and workgroup (96 -> 96 at 64 x 64, tools/wgrad_only_bench.py and its half-MFMA knock-out):
-  // 2.1 us that every pair pays (DMA of both images, the dy fragments, barriers) + 0.42 us per 16-channel input tile: a 32-channel block costs
-  // 2.9 us against 3.8 -- workgroups go to the pairs in proportion to (input-channel tiles + 5), in units of 8 (one per XCD).  (In proportion
-  // to the MFMA counts alone -- 5 : 3 -- the light pairs became the long pole: 119 -> 134 us.)
-  p.npairs = 0;
-  {
-    static int uneven = -1;
-    if (uneven < 0) { const char* e = getenv("DD_WGRAD_BALANCE"); uneven = e ? atoi(e) : 1; }
-    const int np = p.nblk * p.nblk_co, units = bwd_cus() / 8;
-    if (uneven && !a->dx && np > 1 && np <= BW_MAX_PAIRS && np <= units && total_tiles >= 8L * units) {
-      int w[BW_MAX_PAIRS], u[BW_MAX_PAIRS], wsum = 0, used = 0;
-      for (int i = 0; i < np; ++i) {
-        const int cb = i % p.nblk, nci = (a->cin - cb * 64 + 15) / 16;
-        w[i] = (nci < 4 ? nci : 4) + 5;
-        wsum += w[i];
-      }
-      for (int i = 0; i < np; ++i) { u[i] = units * w[i] / wsum; if (u[i] < 1) u[i] = 1; used += u[i]; }
-      for (int pass = 0; used != units && pass < 4 * units; ++pass) {      // leftover units to the heaviest pairs first (surplus from the largest)
-        int best = 0;
-        for (int i = 1; i < np; ++i)
-          if (used < units ? (w[i] * u[best] > w[best] * u[i]) : (u[i] > u[best])) best = i;      // fewest units per weight / most units
-        if (used < units) { ++u[best]; ++used; } else if (u[best] > 1) { --u[best]; --used; } else break;
-      }
-      p.npairs = np;
-      p.wg_start[0] = 0;
-      for (int i = 0; i < np; ++i) p.wg_start[i + 1] = (unsigned short)(p.wg_start[i] + 8 * u[i]);
-    }
-  }
   for (int l = 0; l < n_launch; ++l) {
     p.co_base = l * 64;
     p.accumulate = a->accumulate || l > 0;
