@@ -64,6 +64,23 @@ def measured_traffic(B, dtype):
     return None
 
 
+def hbm_copy_rate(device, nbytes=1 << 30, reps=5):
+    """What HBM delivers to a plain streaming copy on THIS box (read + write of `nbytes` each way, far beyond the 256 MB infinity cache), GB/s.
+    The rooflines keep the guide's 8 TB/s peak; this is the practical ceiling a fused kernel's algorithmic bytes can be read against."""
+    src = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    del src, dst
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def family_bytes(launches, family, esz):
     """Algorithmic HBM bytes of the TIMED launches of one family (the per-launch records profile_ops returns -- the same list the family's time
     and flops come from): every input and output element once, plus the output-shaped operands a launch reads (ReLU mask, residual, the
@@ -474,9 +491,20 @@ def main():
                 "hbm_view": {"achieved": alg_bytes / n / (1e-3 * ms / n) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": alg_bytes / n / (1e-3 * ms / n) / 1e9 / PEAK_HBM_GBS,
                              "flop_per_byte": flops / alg_bytes, "ridge_flop_per_byte": 1e3 * peak / PEAK_HBM_GBS},
+                # the practical ceilings of this box, measured in the same process: a plain 1 GiB copy (torch, read + write), and the family's
+                # slowest-roof estimate -- its algorithmic bytes at that copy rate against its time (a launch that is also at the MFMA ridge
+                # cannot beat either).  The 64 -> 64 layers at 128 x 128 move 537 MB in ~125 us: the copy rate itself
+                "practical": None,
                 "other_kernels_ms_per_step": {k: round(v[1], 3) for k, v in times.items() if k != fam}}
         # every MFMA conv family of the step (conv_bwd = the fused data + weight gradient launch of csrc/dd_conv_bwd.hip, conv_wgrad = the
         # weight-gradient launches of the layers it does not cover) and their aggregate: the step's conv FLOPs over the time of all of them
+        try:
+            cr = hbm_copy_rate(device)
+            roof["practical"] = {"hbm_copy_GBs": cr, "hbm_copy_frac_of_peak": cr / PEAK_HBM_GBS,
+                                 "family_bytes_at_copy_rate_ms": alg_bytes / cr / 1e6, "family_ms": ms,
+                                 "frac_of_copy_rate": (alg_bytes / (1e-3 * ms) / 1e9) / cr}
+        except Exception as e:
+            roof["practical"] = {"error": repr(e)}
         convs = {k: times[k] for k in ("conv_igemm", "conv_bwd", "conv_wgrad") if k in times and times[k][1] > 0}
         roof["mfma_families"] = {k: {"launches_per_step": v[0], "ms_per_step": round(v[1], 3), "tflops": v[2] / (v[1] * 1e-3) / 1e12,
                                      "frac": v[2] / (v[1] * 1e-3) / 1e12 / peak} for k, v in convs.items()}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dd_hip.h"
@@ -221,6 +222,50 @@ template <> __device__ __forceinline__ f32x4_t mma16<float>(uint4 a, uint4 b, f3
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   return c;
+}
+
+// ------------------------------------------------------------------------------------------------ deterministic reductions (DD_DETERMINISTIC=1)
+// Every weight / bias / loss reduction across workgroups ends in fp32 atomics: the sum's ORDER depends on which workgroup finishes first, so two runs
+// of the same step differ in the last bits (and after an optimizer step, everywhere).  With DD_DETERMINISTIC=1 in the environment the workgroups of
+// a launch take turns: workgroup b spins on a ticket until it reads b, issues its atomics, waits until they have been performed (agent-scope
+// release), and hands the ticket to b + 1 (the last one resets it for the next launch).  Every address then receives the workgroups' partial sums in
+// workgroup order -- bit-reproducible run to run; a debugging mode: the flushes of a launch are serialised (a step takes several times longer).
+// Per translation unit: its own ticket (kernels of one stream run one after the other), set up by dd_det_sync() from the launcher; nothing
+// is read or written on the default path beyond one load of the mode word in front of a flush.  Workgroups are dispatched in index order, so
+// the workgroup a ticket waits for is always resident or finished.
+static __device__ unsigned dd_det_state[2];      // [0] = mode on, [1] = ticket
+__device__ __forceinline__ bool dd_det_on() { return __hip_atomic_load(&dd_det_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+__device__ __forceinline__ unsigned dd_det_block() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+// in front of a wave's atomics (any number of times per launch; wave-uniform control flow)
+__device__ __forceinline__ void dd_det_wait() {
+  if (!dd_det_on()) return;
+  const unsigned b = dd_det_block();
+  while (__hip_atomic_load(&dd_det_state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != b) __builtin_amdgcn_s_sleep(8);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// at the END of the kernel, reached by every thread of the workgroup (also by waves that had nothing to add)
+__device__ __forceinline__ void dd_det_end() {
+  if (!dd_det_on()) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the fence's own wait: MI355X_MICROARCH.md, compiler hazard)
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    const unsigned b = dd_det_block(), nb = gridDim.x * gridDim.y * gridDim.z;
+    __hip_atomic_store(&dd_det_state[1], b + 1 == nb ? 0u : b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// host: before launching a kernel with atomics (reads the environment once; arms the mode word of this translation unit once per device)
+static inline void dd_det_sync() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("DD_DETERMINISTIC"); env = (e && e[0] && e[0] != '0') ? 1 : 0; }
+  if (!env) return;
+  static unsigned long long armed = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if ((armed >> (dev & 63)) & 1ull) return;
+  const unsigned init[2] = {1u, 0u};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_det_state), init, sizeof(init));
+  armed |= 1ull << (dev & 63);
 }
 
 // Host-side dispatch on the storage dtype: `T` is float / bf16_t / f16_t inside the statement.

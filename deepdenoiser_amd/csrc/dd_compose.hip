@@ -810,6 +810,7 @@ __device__ __forceinline__ void bwd_role(const ComposeBwdP& p, const BwdLds& m, 
   }
 
   if (WROLE) {            // flush: one atomic per weight-gradient element per workgroup
+    dd_det_wait();        // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
 #pragma unroll
     for (int l = 0; l < 4; ++l)
 #pragma unroll
@@ -880,6 +881,7 @@ __global__ __launch_bounds__(BWD_THREADS) void compose_bwd_kernel(const ComposeB
     red[(tid - W1_FIRST) * 9 + 8] = accb6;
   }
   __syncthreads();
+  dd_det_wait();
   if (tid < 24 * 9) {
     const int n = tid / 9, k = tid - n * 9;
     float s = 0.f;
@@ -889,6 +891,7 @@ __global__ __launch_bounds__(BWD_THREADS) void compose_bwd_kernel(const ComposeB
     else if (k == 7) atomicAdd(p.dw_out + n, s);
     else if (n == 0) atomicAdd(p.db_out, s);
   }
+  dd_det_end();
 }
 
 }  // namespace
@@ -979,9 +982,11 @@ extern "C" int dd_compose_net_bwd(const dd_compose_bwd_args* a, dd_stream stream
   const int grid = p.total_tiles < cus ? p.total_tiles : cus;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == DD_BF16) {
+    dd_det_sync();
     dd_allow_max_lds(reinterpret_cast<const void*>(compose_bwd_kernel<bf16_t>));
     hipLaunchKernelGGL(compose_bwd_kernel<bf16_t>, dim3(grid), dim3(BWD_THREADS), LDS_BWD, s, p);
   } else {
+    dd_det_sync();
     dd_allow_max_lds(reinterpret_cast<const void*>(compose_bwd_kernel<f16_t>));
     hipLaunchKernelGGL(compose_bwd_kernel<f16_t>, dim3(grid), dim3(BWD_THREADS), LDS_BWD, s, p);
   }

@@ -426,7 +426,9 @@ __device__ __forceinline__ void cb_role(const CbP& p, char* smem, char* aux, cha
   }
 }
 
-template <typename T, bool R1>
+// RR = rows per step (128 / strip width): 1, 2 or 4 -- a template parameter since round 5: with a runtime row count every wave carried the three
+// row roles (9 / 4 / 0 MFMAs in front of the barrier) of its layer, and the two-row instantiation spilled 25 - 33 registers (56 B of scratch per lane)
+template <typename T, int RR>
 __global__ __launch_bounds__(1024) void compose_stream_bwd_kernel(const CbP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = sfl(tid >> 6);
@@ -444,8 +446,8 @@ __global__ __launch_bounds__(1024) void compose_stream_bwd_kernel(const CbP p) {
   const int r = t / p.TPR;
 #define CB_ROLE(L)                                                                                        \
   do {                                                                                                    \
-    if (R1 || r == 0) cb_role<T, L, 9>(p, smem, aux, tail, ring_bytes, t, lane, u0, nunits, steps);       \
-    else if (r == 1) cb_role<T, L, 4>(p, smem, aux, tail, ring_bytes, t, lane, u0, nunits, steps);        \
+    if (RR == 1 || r == 0) cb_role<T, L, 9>(p, smem, aux, tail, ring_bytes, t, lane, u0, nunits, steps);  \
+    else if (RR == 2 || r == 1) cb_role<T, L, 4>(p, smem, aux, tail, ring_bytes, t, lane, u0, nunits, steps); \
     else cb_role<T, L, 0>(p, smem, aux, tail, ring_bytes, t, lane, u0, nunits, steps);                    \
   } while (0)
   if (layer == 0) CB_ROLE(0);
@@ -483,13 +485,15 @@ int dd_compose_stream_bwd_data_launch(const dd_compose_bwd_args* a, void* scratc
   p.units = a->N * p.n_strips * p.nb;
   const int grid = p.units < cus ? p.units : cus;
   const int lds = (10 * p.R + 8) * (p.FW + 2) * PIXB + AUX_BYTES + (2 * p.R + 2) * p.FW * TAILB;
-#define CB_LAUNCH(T, R1)                                                                              \
+#define CB_LAUNCH(T, RR)                                                                              \
   do {                                                                                                \
-    dd_allow_max_lds(reinterpret_cast<const void*>(compose_stream_bwd_kernel<T, R1>));                \
-    hipLaunchKernelGGL((compose_stream_bwd_kernel<T, R1>), dim3(grid), dim3(1024), lds, s, p);        \
+    dd_allow_max_lds(reinterpret_cast<const void*>(compose_stream_bwd_kernel<T, RR>));                \
+    hipLaunchKernelGGL((compose_stream_bwd_kernel<T, RR>), dim3(grid), dim3(1024), lds, s, p);        \
   } while (0)
-  if (a->dtype == DD_BF16) { if (p.R == 1) CB_LAUNCH(bf16_t, true); else CB_LAUNCH(bf16_t, false); }
-  else { if (p.R == 1) CB_LAUNCH(f16_t, true); else CB_LAUNCH(f16_t, false); }
+#define CB_LAUNCH_R(T) do { if (p.R == 1) CB_LAUNCH(T, 1); else if (p.R == 2) CB_LAUNCH(T, 2); else CB_LAUNCH(T, 4); } while (0)
+  DD_REQUIRE(p.R == 1 || p.R == 2 || p.R == 4, "dd_compose_net_bwd: %d rows per step", p.R);
+  if (a->dtype == DD_BF16) CB_LAUNCH_R(bf16_t); else CB_LAUNCH_R(f16_t);
+#undef CB_LAUNCH_R
 #undef CB_LAUNCH
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -699,6 +703,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void compose_stream_wgrad_kernel(con
   }
 
   // ---- flush: one atomic per gradient element per workgroup
+  dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
   if (u1 > u0) {
     float* dw = p.dw_res[layer];
 #pragma unroll
@@ -733,6 +738,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void compose_stream_wgrad_kernel(con
       }
     }
   }
+  dd_det_end();
 }
 
 }  // namespace
@@ -769,6 +775,7 @@ int dd_compose_stream_wgrad_launch(const dd_compose_bwd_args* a, void* scratch, 
   p.units = a->N * p.strips * p.nb;
   const int grid = p.units < cus ? p.units : cus;
   constexpr int LDS = CW_LDS;
+  dd_det_sync();
   if (a->dtype == DD_BF16) {
     dd_allow_max_lds(reinterpret_cast<const void*>(compose_stream_wgrad_kernel<bf16_t>));
     hipLaunchKernelGGL(compose_stream_wgrad_kernel<bf16_t>, dim3(grid), dim3(WG_WAVES * 64), LDS, s, p);

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (see bw_mma_inplace)
     // flush: D[t][i] rows = input channels i*16 + q4 + e, column = output channel wr*16 + li; shifted-dy tap t is TensorFlow's tap 8 - t
+    dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
     if (active) {
       const int co = ob * 64 + wr * 16 + li;
       if (co < a.cout) {
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
       }
     }
   }
+  dd_det_end();
 }
 
 static int bwd_cus() {
@@ -407,6 +409,7 @@ static int bwd_cus() {
 template <typename T, bool MASK, bool ACCUM>
 int launch_bwd_flags(const BwdP& p, hipStream_t stream) {
   const size_t lds = 2 * (size_t)BW_BUF;
+  dd_det_sync();
   dd_allow_max_lds(reinterpret_cast<const void*>(conv_bwd_kernel<T, MASK, ACCUM>));
   const long blocks = (long)p.nblk * p.nblk_co * p.ksplit;
   hipLaunchKernelGGL((conv_bwd_kernel<T, MASK, ACCUM>), dim3((unsigned)blocks), dim3(512), lds, stream, p);

@@ -515,6 +515,7 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(const PwgP a) {
   }
   // accumulator (i, jn), lane (li = lane & 15, q = lane >> 4): out[m = mb*MB + (wm*CTM + i)*16 + q*4 + e][n = nb*NB + (wn*CTN + jn)*16 + li]
   const int li = lane & 15, q4 = (lane >> 4) * 4;
+  dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
   if (u0 < u1) {
 #pragma unroll
     for (int i = 0; i < CTM; ++i)
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(const PwgP a) {
       }
     }
   }
+  dd_det_end();
 }
 
 struct PwgCfg { int ctm, ctn; };
@@ -556,6 +558,7 @@ constexpr PwgCfg PWG_CFGS[] = {{4, 8}, {5, 5}, {3, 6}, {2, 3}, {5, 1}, {5, 2}, {
 template <typename T, int CTM, int CTN>
 void wgrad_pw_launch_cfg(const PwgP& p, unsigned grid, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(CTM + (CTN + 1) / 2) * 64 * DD_LDS_ROW;
+  dd_det_sync();
   if (p.g9_cp) {
     dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_pw_kernel<T, CTM, CTN, true>));
     hipLaunchKernelGGL((wgrad_pw_kernel<T, CTM, CTN, true>), dim3(grid), dim3(512), lds, s, p);

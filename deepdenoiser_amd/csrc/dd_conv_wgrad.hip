@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
   }
 
   WPHASE_T(e0);
+  dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
   // D[m][n]: lane holds n = lane&15, m = (lane>>4)*4 + e
   const int li = lane & 15, q4 = (lane >> 4) * 4;
 #pragma unroll
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP a) {
       if (c < (bias_q ? a.n : a.m)) atomicAdd(a.bias_out + c, s);
     }
   }
+  dd_det_end();
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
   }
 
   WPHASE_T(e0);
+  dd_det_wait();
   const int li = lane & 15, q4 = (lane >> 4) * 4;
 #pragma unroll
   for (int i = 0; i < TW; ++i) {
@@ -660,11 +663,13 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
 #ifdef DD_PROFILE_PHASES
   if (blockIdx.x == 0 && tid == 0) { dd_wphase_cycles[14] += __builtin_readcyclecounter() - k_t0; dd_wphase_cycles[15] += wall_clock64() - k_w0; }
 #endif
+  dd_det_end();
 }
 
 template <typename T, bool IN_RELU, int MODE>
 static void launch_dma_mode(const WgradP& p, long blocks, hipStream_t stream) {
   const size_t lds = 2 * (size_t)WgLds<MODE != 2>::BUF;
+  dd_det_sync();
   dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_dma_kernel<T, IN_RELU, MODE>));
   hipLaunchKernelGGL((wgrad_dma_kernel<T, IN_RELU, MODE>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
 }
@@ -708,6 +713,7 @@ int launch(const WgradP& p, hipStream_t stream) {
   const size_t lds = (size_t)PH * PH * DD_LDS_ROW + (size_t)DD_TILE * DD_TILE * DD_LDS_ROW;
   dd_allow_max_lds(reinterpret_cast<const void*>(wgrad_kernel<T, TAPS>), 96 * 1024);
   const long blocks = (long)p.ksplit * p.mslices * p.nslices;
+  dd_det_sync();
   hipLaunchKernelGGL((wgrad_kernel<T, TAPS>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
   DD_LAUNCH_CHECK();
   return DD_OK;

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (see ct_mma_inplace)
   // flush: D[j][i] rows = output channels (h*JW + j)*16 + q*4 + e, column = input channel i*16 + li; TensorFlow layout [a][b][co][ci]
+  dd_det_wait();
   if (w_active) {
 #pragma unroll
     for (int j = 0; j < JW; ++j)
@@ -381,7 +382,12 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
           if (co < a.cout) atomicAdd(a.dw + ((long)tw * a.cout_total + a.co_off + co) * a.cin + ci, wacc[j][i][e]);
         }
       }
-    if (a.db) {
+  }
+  // bias gradient: the four tap waves of an output-channel half each hold the sum over their own quarter of the output pixels -- four adds to one
+  // address from one workgroup; in deterministic mode they go in tap order (a barrier between them: every wave of the workgroup is here)
+  const bool det = dd_det_on();
+  for (int turn = 0; turn < (det ? 4 : 1); ++turn) {
+    if (w_active && a.db && (!det || tw == turn)) {
 #pragma unroll
       for (int j = 0; j < JW; ++j) {
         float b = bsum[j];
@@ -391,7 +397,9 @@ __global__ __launch_bounds__(512) void convt_bwd_kernel(const CtP a) {
         if (lane < 16 && co < a.cout) atomicAdd(a.db + a.co_off + co, b);
       }
     }
+    if (det) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
   }
+  dd_det_end();
 }
 
 static int ct_cus() {
@@ -400,6 +408,7 @@ static int ct_cus() {
 
 template <typename K>
 static void ct_launch(K kernel, const CtP& p, size_t lds, hipStream_t stream) {
+  dd_det_sync();
   dd_allow_max_lds(reinterpret_cast<const void*>(kernel));
   hipLaunchKernelGGL(kernel, dim3((unsigned)p.nwg), dim3(512), lds, stream, p);
 }

@@ -626,6 +626,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
   // 256 threads walk the summed tiles: thread -> (element e, lane) of a tile, exactly the layout above
   const int fl = threadIdx.x & 63, fe = threadIdx.x >> 6, fli = fl & 15, fq = fl >> 4;
 #ifndef HB_EXP_NO_FLUSH
+  dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
   if (threadIdx.x < 256) {
     int t = 0;
     for (int i = 0; i < NPT; ++i)
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
   }
 #endif
   HPH(7);
+  dd_det_end();
 }
 
 static int head_cus() { return dd_device_cus(); }
@@ -667,6 +669,7 @@ int launch_head(const HeadP& p, bool backward, hipStream_t s) {
   } else {
     constexpr int STRIP = 32 * (3 * 64 + NCH * 64);
     const size_t lds = BWD_WAVES * (size_t)STRIP + (size_t)(HeadDim<KS>::NT * NCH + NCH * 2 + 4 * HeadDim<KS>::NT) * 1024;
+    dd_det_sync();
     dd_allow_max_lds(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, false>));
     dd_allow_max_lds(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, true>));
     long wgs = (long)head_cus();                       // persistent: one flush of the gradient tiles per workgroup

@@ -147,11 +147,14 @@ __global__ void colsum_kernel(const T* __restrict__ x, int ld, int c, long rows,
     for (long r = (long)blockIdx.x * 4 + rl; r < rows; r += (long)gridDim.x * 4) s += ld1<T>(x + r * ld + ch);
   partial[threadIdx.x] = s;
   __syncthreads();
+  dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups add in index order, dd_common.h)
   if (rl == 0 && ch < c) atomicAdd(out + ch, partial[ci] + partial[64 + ci] + partial[128 + ci] + partial[192 + ci]);
+  dd_det_end();
 }
 extern "C" int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream) {
   DD_REQUIRE(x && out && c > 0 && rows > 0, "dd_colsum: bad arguments");
   dim3 g((unsigned)min((rows + 3) / 4, 1024L), (unsigned)((c + 63) / 64));
+  dd_det_sync();
   DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, g, dim3(256), 0, S(stream), (const T*)x, ld, c, rows, out));
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -1314,9 +1317,10 @@ __global__ void loss_mask_sums_kernel(const dd_loss_desc d, long npix, float* __
       if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0 && red[0] != 0.f) atomicAdd(sums + src, red[0]);
+    if (threadIdx.x == 0 && red[0] != 0.f) { dd_det_wait(); atomicAdd(sums + src, red[0]); }
     __syncthreads();
   }
+  dd_det_end();
 }
 extern "C" int dd_loss_mask_sums(const dd_loss_desc* desc, int B, int H, int W, float* mask_sums, dd_stream stream) {
   DD_REQUIRE(desc && mask_sums && desc->n_features > 0 && desc->n_features <= DD_MAX_FEATURES && desc->n_combined <= DD_MAX_COMBINED,
@@ -1326,6 +1330,7 @@ extern "C" int dd_loss_mask_sums(const dd_loss_desc* desc, int B, int H, int W, 
     dd_set_error("dd_loss_mask_sums: hipMemsetAsync failed");
     return DD_ERR_LAUNCH;
   }
+  dd_det_sync();
   hipLaunchKernelGGL(loss_mask_sums_kernel, dim3(grid_for(npix)), dim3(256), 0, S(stream), *desc, npix, mask_sums);
   DD_LAUNCH_CHECK();
   return DD_OK;
@@ -1383,7 +1388,8 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, 
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(loss_out, red[0]);
+  if (threadIdx.x == 0) { dd_det_wait(); atomicAdd(loss_out, red[0]); }
+  dd_det_end();
 }
 extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float* loss_out, float grad_scale, dd_stream stream) {
   DD_REQUIRE(desc && loss_out && desc->n_features > 0 && desc->n_features <= DD_MAX_FEATURES && desc->n_combined <= DD_MAX_COMBINED,
@@ -1391,6 +1397,7 @@ extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float
   DD_REQUIRE(desc->kind >= 1 && desc->kind <= 5, "dd_loss_head: unknown loss kind %d", desc->kind);
   const long npix = (long)B * H * W;
   const long npairs = (long)B * ((long)H * (W - 1) + (long)(H - 1) * W);
+  dd_det_sync();
   hipLaunchKernelGGL(loss_head_kernel, dim3(min(grid_for(npix), 2048u)), dim3(256), 0, S(stream), *desc, npix, H, W, 1.f / (float)npix,
                      npairs > 0 ? 1.f / (float)npairs : 0.f, grad_scale, loss_out);
   DD_LAUNCH_CHECK();
