@@ -29,6 +29,17 @@ for name in ("bench.json", "kernel_stats.txt", "inference.json", "host_inputs.tx
             shutil.copy(p, out)
 
 
+# every oracle comparison of the round's -m gpu session with its measured error and its gate (tests/conftest.py writes them to gpurun_out/),
+# the child-process sessions of tests/test_gpu_fallbacks.py beside it (the round's parity log belongs in the tracked tree)
+import glob
+for pth in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "parity_errors*.txt"))):
+    shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag.split("_")[0], os.path.basename(pth))))
+for name in ("rw_loop_ubench.txt", "lds_probe.txt", "sq_table.txt", "wgrad_only_knockouts.txt", "deterministic.txt"):
+    pth = os.path.join(src, name)
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag, name)))
+
+
 def family(path):
     fam = {}
     for line in open(path):

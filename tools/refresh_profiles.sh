@@ -40,5 +40,11 @@ done
 HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_DEVICE=0 DD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 3 --batch 32 > $out/two_ranks_one_gpu.txt 2> $out/two_ranks_one_gpu.err
 # one rank over RCCL (the nccl backend): communicator, side-stream all-reduces, barriers -- functional record, not a scaling number
 HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $out/one_rank_rccl.txt 2> $out/one_rank_rccl.err
+# round 5: the microbenchmarks and knock-outs DESIGN section 7 cites (tools/exp/* are built on the CPU side before the call)
+[ -x tools/exp/rw_loop_ubench ] && tools/exp/rw_loop_ubench > $out/rw_loop_ubench.txt 2>&1
+[ -x tools/exp/lds_probe ] && tools/exp/lds_probe > $out/lds_probe.txt 2>&1
+tools/pmc_sq_table.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_table.txt $out/sq_table.txt
+( for v in hip nodma0 nowrole noflush0; do echo "== $v"; if [ $v = hip ]; then python tools/wgrad_only_bench.py 2>/dev/null; elif [ -f tools/exp/libdd_$v.so ]; then DD_LIB=tools/exp/libdd_$v.so python tools/wgrad_only_bench.py 2>/dev/null; fi; done ) > $out/wgrad_only_knockouts.txt 2>&1
+( DD_DETERMINISTIC=1 python tools/det_diag.py cfg2; python tools/det_diag.py cfg2 ) > $out/deterministic.txt 2>&1
 rm -rf $out/prof $out/prof_inf $out/prof_cfg3 $out/prof_cfg3l $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 cat $out/smoke.txt | tail -2; cut -c1-300 $out/bench.json; cat $out/pmc_*.txt; head -12 $out/kernel_stats.txt
