@@ -324,6 +324,20 @@ __device__ __forceinline__ uint4 strip_frag_tr(const char* strip, int row_bytes,
   return r;
 }
 
+// Row pitches of a wave's strip.  The 16-byte parking stores of 8 consecutive pixels and the transposing reads of 4 consecutive pixel rows must
+// spread over the banks: with the natural pitches (64 B for the three 32-slot strips, 64 / 128 / 192 / 256 B for x) pixels p and p + 4 (64 B) or
+// p + 2 (128 B) share their banks -- SQ_LDS_BANK_CONFLICT was 59 % of the LDS cycles of the 64-channel instantiation.  112 B (28 dwords) and
+// x + 16 B keep both patterns apart (the bank model is in DESIGN 3.4); the 128-channel instantiation keeps the natural pitches (it has no
+// register left for the odd multiples: 9 spilled with them).
+template <int NCH> struct HeadStrip {
+#ifdef HB_EXP_NATURAL_PITCH      // (experiment builds, tools/build_variant.sh: the pitches of rounds 2-4)
+  static constexpr int HROW = 64, XROW = NCH * 64;
+#else
+  static constexpr int HROW = NCH <= 3 ? 112 : 64;
+  static constexpr int XROW = NCH == 1 ? 112 : (NCH <= 3 ? NCH * 64 + 16 : NCH * 64);
+#endif
+  static constexpr int BYTES = 32 * (3 * HROW + XROW);
+};
 constexpr int BWD_WAVES = 8;      // one persistent workgroup per CU, 2 waves per SIMD (a wave's 32-pixel step is a chain of memory round trips)
 // ACCUM (d x is added to a gradient already stored) is a template flag: as a runtime branch the never-taken side still cost the 2 * NCH * 2
 // registers of the old gradient, and the 128-channel instantiation spilled 55 registers (round 2).
@@ -331,14 +345,14 @@ template <typename T, int KS, int NCH, bool ACCUM>
 __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a) {
   constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, P = HeadDim<KS>::P, ONES = HeadDim<KS>::ONES_POS;
   constexpr int CT = NCH * 2;                          // 16-channel tiles of x
-  constexpr int XROW = NCH * 64, STRIP = 32 * (3 * 64 + XROW);
+  constexpr int XROW = HeadStrip<NCH>::XROW, HROW = HeadStrip<NCH>::HROW, STRIP = HeadStrip<NCH>::BYTES;
   constexpr int NA1 = HeadDim<KS>::NT * NCH;           // fragment-ready operand image behind the strips (forward_gemms_lds): a1, a4, a3, a2, b1, b2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* s_hid = smem + wv * STRIP;                     // [32 px][32 slots] hid (slot order, position ONES := 1)
-  char* s_dl = s_hid + 32 * 64;                        // [32 px][32 slots] d logits
-  char* s_dh = s_dl + 32 * 64;                         // [32 px][32 slots] d hid (pre-activation)
-  char* s_x = s_dh + 32 * 64;                          // [32 px][NCH * 32 channels] x
+  char* s_dl = s_hid + 32 * HROW;                      // [32 px][32 slots] d logits
+  char* s_dh = s_dl + 32 * HROW;                       // [32 px][32 slots] d hid (pre-activation)
+  char* s_x = s_dh + 32 * HROW;                        // [32 px][NCH * 32 channels] x      (rows HROW / XROW bytes apart: HeadStrip)
   const long wave = (long)blockIdx.x * BWD_WAVES + wv, nwaves = (long)gridDim.x * BWD_WAVES;
 
   HPH_DECL();
@@ -549,11 +563,11 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
         else hs.w = (hs.w & keep) | one;
       }
       // (one opaque base per strip: left alone hipcc keeps a lane-constant address register per store alive across the whole loop)
-      int park = row * 64 + q * 16;
+      int park = row * HROW + q * 16;
       asm volatile("" : "+v"(park));
       *reinterpret_cast<uint4*>(s_hid + park) = hs;
-      *reinterpret_cast<uint4*>(s_hid + 32 * 64 + park) = keep4(dl);
-      *reinterpret_cast<uint4*>(s_hid + 2 * 32 * 64 + park) = keep4(dh);
+      *reinterpret_cast<uint4*>(s_hid + 32 * HROW + park) = keep4(dl);
+      *reinterpret_cast<uint4*>(s_hid + 2 * 32 * HROW + park) = keep4(dh);
       int parkx = row * XROW + q * 16;
       asm volatile("" : "+v"(parkx));
 #pragma unroll
@@ -566,10 +580,10 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
     // weight gradients over these 32 pixels
     uint4 fdl[NPT], fdh[NPT];
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) { fdl[j] = strip_frag_tr(s_dl, 64, j, lane); fdh[j] = strip_frag_tr(s_dh, 64, j, lane); }
+    for (int j = 0; j < NPT; ++j) { fdl[j] = strip_frag_tr(s_dl, HROW, j, lane); fdh[j] = strip_frag_tr(s_dh, HROW, j, lane); }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const uint4 fh = strip_frag_tr(s_hid, 64, i, lane);
+      const uint4 fh = strip_frag_tr(s_hid, HROW, i, lane);
 #pragma unroll
       for (int j = 0; j < NPT; ++j) g_wb[i][j] = mma16<T>(fh, fdl[j], g_wb[i][j]);         // dWb[pos m][pos n] (row ONES: d bb)
       if (i == (ONES >> 4)) {
@@ -667,7 +681,7 @@ int launch_head(const HeadP& p, bool backward, hipStream_t s) {
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL((head_fwd_kernel<T, KS, NCH>), dim3((unsigned)wgs), dim3(256), 0, s, p);
   } else {
-    constexpr int STRIP = 32 * (3 * 64 + NCH * 64);
+    constexpr int STRIP = HeadStrip<NCH>::BYTES;
     const size_t lds = BWD_WAVES * (size_t)STRIP + (size_t)(HeadDim<KS>::NT * NCH + NCH * 2 + 4 * HeadDim<KS>::NT) * 1024;
     dd_det_sync();
     dd_allow_max_lds(reinterpret_cast<const void*>(head_bwd_kernel<T, KS, NCH, false>));

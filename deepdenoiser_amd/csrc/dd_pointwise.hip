@@ -571,7 +571,7 @@ template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, float a, float 
 
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_entry* __restrict__ table, int n_entries, T* __restrict__ dst, int ld, int c_pad,
-                                                             int B, int H, int W, int tiles_x, int tiles_y) {
+                                                             int B, int H, int W, int tiles_x, int tiles_y, const int* __restrict__ origins, int frame_pitch) {
   constexpr int TP = 16, HP = TP + 2;
   __shared__ float s_std[3][HP][HP + 1];
   __shared__ float s_var[3][HP][HP + 1];
@@ -586,6 +586,12 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
   const int y = y0 + ly, x = x0 + lx;
   const bool live = y < H && x < W;
   const long pix = ((long)b * H + (live ? y : 0)) * W + (live ? x : 0);
+  // Where image b of a render pass starts and how far its rows are apart (pixels): a [B,H,W,cs] batch of tiles, or -- origins != NULL, the
+  // inference path -- the H x W window at (origins[2b], origins[2b+1]) of a whole frame whose rows are frame_pitch pixels long (the halo tile
+  // of Prediction.py:396-427 read in place: dd_extract_tiles and the tile copies of the passes are gone).  The mirrored 3x3 neighbourhood
+  // stays inside the window either way: the reference takes the variance of the TILE.
+  const int pitch = origins ? frame_pitch : W;
+  const long img_pix = origins ? (long)origins[2 * b] * frame_pitch + origins[2 * b + 1] : (long)b * H * W;
   // a pixel's row is c_pad elements + 4 bytes: with rows of exactly 64 bytes (32 bf16 channels) the 64 lanes of a wave, each storing into its own
   // row, hit 4 bank groups; 68 bytes = 17 banks spreads them over all 64
   const int rstride = c_pad + 4 / (int)sizeof(T);
@@ -599,14 +605,14 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
     const int k = threadIdx.x + it * 256;
     const int py = k / HP, px = k - py * HP;
     const int gy = sym_index(min(y0 - 1 + min(py, HP - 1), H), H), gx = sym_index(min(x0 - 1 + px, W), W);
-    hoff[it] = gy * W + gx;
+    hoff[it] = gy * pitch + gx;
   }
   float raw[2][3];
   auto is_pass = [&](int e) { return e < n_entries && table[t * n_entries + e].nch > 0 && table[t * n_entries + e].kind == 0; };
   auto request = [&](int e) {
     const dd_assemble_entry en = table[t * n_entries + e];
     const int cs = en.cs;
-    const float* img = en.src + (long)b * H * W * cs;
+    const float* img = en.src + img_pix * cs;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const float* sp = img + (long)hoff[it] * cs;
@@ -732,8 +738,8 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const dd_assemble_e
     }
   }
 }
-extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
-                                 int B, int H, int W, int dtype, dd_stream stream) {
+static int assemble_common(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                           int B, int H, int W, int dtype, const int* origins, int frame_pitch, dd_stream stream) {
   DD_REQUIRE(table && dst && n_tuples > 0 && n_entries > 0 && c_pad > 0 && c_pad <= ld, "dd_assemble_input: bad arguments");
   DD_REQUIRE(dd_dtype_ok(dtype), "dd_assemble_input: bad dtype %d", dtype);
   const int per16 = dtype == DD_F32 ? 4 : 8, esz = dtype == DD_F32 ? 4 : 2;
@@ -744,10 +750,21 @@ extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, i
   const unsigned grid = (unsigned)((long)n_tuples * B * tiles_x * tiles_y);
   DD_DISPATCH_DTYPE(dtype, T, {
     dd_allow_max_lds(reinterpret_cast<const void*>(assemble_input_kernel<T>), 96 * 1024);
-    hipLaunchKernelGGL(assemble_input_kernel<T>, dim3(grid), dim3(256), lds, S(stream), table, n_entries, (T*)dst, ld, c_pad, B, H, W, tiles_x, tiles_y);
+    hipLaunchKernelGGL(assemble_input_kernel<T>, dim3(grid), dim3(256), lds, S(stream), table, n_entries, (T*)dst, ld, c_pad, B, H, W, tiles_x, tiles_y,
+                       origins, frame_pitch);
   });
   DD_LAUNCH_CHECK();
   return DD_OK;
+}
+extern "C" int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                                 int B, int H, int W, int dtype, dd_stream stream) {
+  return assemble_common(table, n_tuples, n_entries, dst, ld, c_pad, B, H, W, dtype, nullptr, 0, stream);
+}
+extern "C" int dd_assemble_input_frames(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                                        int B, int H, int W, int dtype, const int* origins_yx, int frame_h, int frame_w, dd_stream stream) {
+  DD_REQUIRE(origins_yx && H > 0 && W > 0 && H <= frame_h && W <= frame_w, "dd_assemble_input_frames: the %dx%d tile does not fit the %dx%d frame (or no origins)",
+             H, W, frame_h, frame_w);
+  return assemble_common(table, n_tuples, n_entries, dst, ld, c_pad, B, H, W, dtype, origins_yx, frame_w, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ kernel prediction
@@ -1391,12 +1408,118 @@ __global__ void loss_head_kernel(const dd_loss_desc d, long npix, int H, int W, 
   if (threadIdx.x == 0) { dd_det_wait(); atomicAdd(loss_out, red[0]); }
   dd_det_end();
 }
+// Features-only fast path (no combined / image / variation / masked terms: every term is a function of one element of one feature): the
+// [B,H,W,3] blocks are walked as flat float4 streams, 2 vectors in flight per thread.  Optionally fused with the inverse standardization on both
+// sides of the loss (FeaturePrediction.prediction_invert_standardization, Architecture.py:134-138 -> Architecture.py:47-55, Utilities.py:3-7):
+// with pred_std[f] set the kernel reads the standardized prediction x, stores p = invert(x) to pred_inv[f], and writes dL/dx instead of
+// dL/dp -- the expressions of invert_std_fwd_kernel / invert_std_bwd_kernel, element for element (three launches per scale become one:
+// 36 -> 16 bytes per element of HBM traffic).
+struct LossSimpleF {
+  const float* x; const float* t; float* p; float* d;
+  float w; float mean, std; int log1p, one_channel, fused;
+};
+struct LossSimpleP { LossSimpleF f[DD_MAX_FEATURES]; int n; int kind; float eps, grad_scale; long nvec; float* loss_out; };
+
+__device__ __forceinline__ void loss_simple_elem(const LossSimpleF& f, int kind, float eps, float gs, bool live, float x, float t, float& p, float& d, float& loss) {
+  float dinv = 1.f;
+  p = x;
+  if (f.fused) {
+    float z = x * f.std + f.mean;
+    dinv = f.std;
+    if (f.log1p) {
+      dinv *= (z != 0.f) ? expf(fabsf(z)) : 0.f;
+      z = z > 0.f ? expm1f(z) : (z < 0.f ? -expm1f(-z) : 0.f);
+    }
+    p = z;
+  }
+  float l, dl;
+  loss_term(kind, eps, p, t, &l, &dl);
+  loss += live ? f.w * l : 0.f;
+  const float g = live ? f.w * dl * gs : 0.f;
+  d = f.fused ? g * dinv : g;
+}
+
+__global__ __launch_bounds__(256) void loss_simple_kernel(const LossSimpleP P) {
+  __shared__ float red[4];
+  float loss = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (int fi = 0; fi < P.n; ++fi) {                      // block-uniform
+    const LossSimpleF f = P.f[fi];
+    const float4* xv = reinterpret_cast<const float4*>(f.x);
+    const float4* tv = reinterpret_cast<const float4*>(f.t);
+    float4* pv = reinterpret_cast<float4*>(f.p);
+    float4* dv = reinterpret_cast<float4*>(f.d);
+    for (long v0 = blockIdx.x * 256L + threadIdx.x; v0 < P.nvec; v0 += 2 * stride) {
+      const long v1 = v0 + stride;
+      const bool has1 = v1 < P.nvec;
+      const float4 xa = xv[v0], ta = tv[v0];
+      const float4 xb = has1 ? xv[v1] : xa, tb = has1 ? tv[v1] : ta;
+      auto one = [&](long v, const float4& x4, const float4& t4) {
+        // element e = 4 v + k of the block is channel e % 3 of its pixel: a 1-channel pass only counts channel 0 (Training.py:116-129)
+        const int c0 = (int)((4 * v) % 3);
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ts[4] = {t4.x, t4.y, t4.z, t4.w};
+        float ps[4], ds[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = c0 + k >= 3 ? (c0 + k >= 6 ? c0 + k - 6 : c0 + k - 3) : c0 + k;
+          loss_simple_elem(f, P.kind, P.eps, P.grad_scale, !f.one_channel || c == 0, xs[k], ts[k], ps[k], ds[k], loss);
+        }
+        if (f.fused) pv[v] = float4{ps[0], ps[1], ps[2], ps[3]};
+        dv[v] = float4{ds[0], ds[1], ds[2], ds[3]};
+      };
+      one(v0, xa, ta);
+      if (has1) one(v1, xb, tb);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) { dd_det_wait(); atomicAdd(P.loss_out, red[0] + red[1] + red[2] + red[3]); }
+  dd_det_end();
+}
+
 extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float* loss_out, float grad_scale, dd_stream stream) {
   DD_REQUIRE(desc && loss_out && desc->n_features > 0 && desc->n_features <= DD_MAX_FEATURES && desc->n_combined <= DD_MAX_COMBINED,
              "dd_loss_head: bad descriptor");
   DD_REQUIRE(desc->kind >= 1 && desc->kind <= 5, "dd_loss_head: unknown loss kind %d", desc->kind);
   const long npix = (long)B * H * W;
   const long npairs = (long)B * ((long)H * (W - 1) + (long)(H - 1) * W);
+  // features-only descriptors take the flat float4 kernel (DD_LOSS_SIMPLE=0: the general kernel); the fused inverse standardization exists
+  // only there
+  bool fused_any = false, simple = desc->n_combined == 0 && (npix * 3) % 4 == 0;
+  if (desc->image_weight != 0.f || desc->image_var_weight != 0.f) simple = simple && desc->n_image_combined == 0 && desc->n_image_features == 0;
+  for (int f = 0; f < desc->n_features; ++f) {
+    fused_any = fused_any || desc->pred_std[f] != nullptr;
+    const bool active = desc->weight[f] != 0.f || desc->pred_std[f] != nullptr;
+    if (desc->var_weight[f] != 0.f || (desc->masked_weight[f] != 0.f && desc->mask_feature[f] >= 0 && desc->mask_sums)) simple = false;
+    if (active && (desc->pred_ld[f] != 3 || desc->target_ld[f] != 3 || (desc->nch[f] != 1 && desc->nch[f] != 3))) simple = false;
+    if (active && (((uintptr_t)desc->pred[f] | (uintptr_t)desc->target[f] | (uintptr_t)desc->dpred[f] | (uintptr_t)desc->pred_std[f] | (uintptr_t)desc->pred_inv[f]) & 15)) simple = false;
+    if (desc->pred_std[f]) DD_REQUIRE(desc->pred_inv[f] && desc->inv_std[f] > 0.f, "dd_loss_head: pred_std[%d] needs pred_inv and a positive inv_std", f);
+  }
+  static const bool simple_on = [] { const char* e = getenv("DD_LOSS_SIMPLE"); return !(e && e[0] == '0'); }();
+  DD_REQUIRE(!fused_any || simple, "dd_loss_head: the fused inverse standardization (pred_std) needs a features-only descriptor "
+             "(no combined / image / variation / masked terms, 3-float pixels, 16-byte aligned blocks)");
+  if (simple && (simple_on || fused_any)) {
+    LossSimpleP P;
+    memset(&P, 0, sizeof(P));
+    for (int f = 0; f < desc->n_features; ++f) {
+      const bool fused = desc->pred_std[f] != nullptr;
+      if (desc->weight[f] == 0.f && !fused) continue;       // generated passes: their scratch dpred stays zero
+      LossSimpleF& o = P.f[P.n++];
+      o.x = fused ? desc->pred_std[f] : desc->pred[f];
+      o.t = desc->target[f]; o.p = fused ? desc->pred_inv[f] : nullptr; o.d = desc->dpred[f];
+      o.w = desc->weight[f] * (1.f / (float)npix);
+      o.mean = desc->inv_mean[f]; o.std = desc->inv_std[f]; o.log1p = desc->inv_log1p[f]; o.one_channel = desc->nch[f] == 1; o.fused = fused;
+    }
+    if (P.n == 0) return DD_OK;
+    P.kind = desc->kind; P.eps = desc->epsilon; P.grad_scale = grad_scale; P.nvec = npix * 3 / 4; P.loss_out = loss_out;
+    dd_det_sync();
+    const long want = (P.nvec + 511) / 512;
+    hipLaunchKernelGGL(loss_simple_kernel, dim3((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), dim3(256), 0, S(stream), P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+  }
   dd_det_sync();
   hipLaunchKernelGGL(loss_head_kernel, dim3(min(grid_for(npix), 2048u)), dim3(256), 0, S(stream), *desc, npix, H, W, 1.f / (float)npix,
                      npairs > 0 ? 1.f / (float)npairs : 0.f, grad_scale, loss_out);

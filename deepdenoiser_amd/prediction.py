@@ -8,6 +8,7 @@ contract), and crop/stitch/recombine run on the device.  EXR decode (cv2) is out
 tensors keyed by the reference's feature names.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -97,12 +98,24 @@ class Predictor:
                 if tuple(fr.shape) != (H, W, prog.flags_raw[name].shape[3]):
                     raise ValueError("%s: expected a [%d,%d,%d] frame, got %s" % (key, H, W, prog.flags_raw[name].shape[3], tuple(fr.shape)))
                 flag_frames[name] = fr
+        # Render passes whose frames have exactly the pass's channels are read in place by the input assembly (no tile copies); anything else
+        # (wider frames, DD_FRAME_INPUT=0, the unfused input path) goes through dd_extract_tiles as before.
+        direct = (prog.fused_input and os.environ.get("DD_FRAME_INPUT", "1") != "0"
+                  and all(frame[Naming.source_feature_name(f.name, index=0)].shape[2] == f.number_of_channels for f in feats))
+        if direct:
+            if prog.frame_input is None:
+                prog.enable_frame_input(H, W)
+            prog.set_frame_sources({f.name: frame[Naming.source_feature_name(f.name, index=0)] for f in feats})
+        elif prog.frame_input is not None:      # (programs are cached per architecture: an earlier frame may have been read in place)
+            prog.disable_frame_input()
         for oyx, tdev, n in chunks:
+            if direct:
+                prog.frame_origins.copy_(oyx, non_blocking=True)
             for name, fr in flag_frames.items():
                 raw = prog.flags_raw[name]
                 L.check(lib.dd_extract_tiles(fr.data_ptr(), H, W, fr.shape[2], fr.shape[2], raw.data_ptr(), T, raw.shape[3],
                                              oyx.data_ptr(), oyx.shape[0], stream))
-            for f in feats:                                              # halo tiles straight into the program's input buffers
+            for f in (() if direct else feats):                         # halo tiles straight into the program's input buffers
                 fr = frame[Naming.source_feature_name(f.name, index=0)]
                 raw = prog.raw[f.name]
                 L.check(lib.dd_extract_tiles(fr.data_ptr(), H, W, fr.shape[2], f.number_of_channels, raw.data_ptr(), T, raw.shape[3],
@@ -123,14 +136,15 @@ class Predictor:
         if not self.use_graph:
             prog.forward(pack=False)
             return
-        gr = self._graphs.get(id(prog))
+        key = (id(prog), prog.frame_input)             # (a graph replays the input-assembly launch it was captured with)
+        gr = self._graphs.get(key)
         if gr is None:
             prog.forward(pack=False)                 # eager once: binds every launch, warms the caches
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 prog.forward(pack=False)
-            self._graphs[id(prog)] = gr
+            self._graphs[key] = gr
         gr.replay()
 
     def _recombine(self, prog, frames, out, npix, stream):

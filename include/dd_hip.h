@@ -218,6 +218,12 @@ int dd_gather_input(const dd_gather_entry* table, int n_tuples, int n_entries, v
 typedef struct { const float* src; int cs; int kind; dd_feature_params fp; int nch; int dst_ch; float* std_out; int ld_std; } dd_assemble_entry;
 int dd_assemble_input(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
                       int B, int H, int W, int dtype, dd_stream stream);
+/* The same launch for full-frame inference (Prediction.py:380-427: every tile is an H x W window of the frame): the kind-0 entries' src are
+ * whole frames [frame_h, frame_w, cs] fp32 and image b of the batch is the window at (origins_yx[2b], origins_yx[2b+1]) (device table,
+ * [B][2] int32, the tile plan's origins) -- read in place, mirrored at the WINDOW's border exactly as a copied tile would be.  Replaces one
+ * dd_extract_tiles per render pass and the tile copies it wrote.  kind-1 / kind-2 entries as in dd_assemble_input. */
+int dd_assemble_input_frames(const dd_assemble_entry* table, int n_tuples, int n_entries, void* dst, int ld, int c_pad,
+                             int B, int H, int W, int dtype, const int* origins_yx, int frame_h, int frame_w, dd_stream stream);
 
 /* ---- kernel prediction (KernelPrediction.kernel_prediction, KernelPrediction.py:11-63): softmax over k*k logits,
  * symmetric pad, per-pixel k x k filter of the 3-channel source. */
@@ -353,6 +359,16 @@ typedef struct {
   float epsilon;
   const float* mask_sums;                /* device, [DD_MAX_FEATURES + DD_MAX_COMBINED]: sum of each source's mask over the batch (dd_loss_mask_sums);
                                             may be NULL when no masked weight is set */
+  /* Optional fusion of FeaturePrediction.prediction_invert_standardization (Architecture.py:134-138, :47-55; Utilities.py:3-7) into the loss
+   * launch, per feature; only for features-only descriptors (n_combined = 0, no image / variation / masked terms, pred_ld = target_ld = 3,
+   * 16-byte aligned blocks) -- anything else is rejected.  With pred_std[f] != NULL the launch reads the STANDARDIZED prediction x from
+   * pred_std[f], stores p = sign(z) expm1|z| (inv_log1p) or z, z = x inv_std + inv_mean, to pred_inv[f] (what dd_invert_std_fwd stores),
+   * and writes dL/dx (what dd_invert_std_bwd stores) to dpred[f] instead of dL/dp; pred[f] is not read. */
+  const float* pred_std[DD_MAX_FEATURES];
+  float* pred_inv[DD_MAX_FEATURES];
+  int inv_log1p[DD_MAX_FEATURES];
+  float inv_mean[DD_MAX_FEATURES];
+  float inv_std[DD_MAX_FEATURES];
 } dd_loss_desc;
 /* mask_sums[src] = sum over [B,H,W] of sign(sum_c |target_c|) of the source's mask feature, for every source with a masked weight
  * (features first, then combined at DD_MAX_FEATURES + k).  The masked mean divides by this BATCH-global count (Training.py:131-137). */

@@ -164,6 +164,51 @@ def test_cfg5_full_frame_1080p_matches_the_oracle_tile_by_tile():
     print("cfg-5 1080p frame vs f64 oracle, rel-L2: " + ", ".join("%s %.3e" % kv for kv in errs.items()))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_frame_input_read_in_place_is_bit_identical_to_extracted_tiles(dtype, monkeypatch):
+    """Inference reads the halo tiles of the render passes in place from the frames (dd_assemble_input_frames, round 5) instead of copying them
+    out with dd_extract_tiles first: same windows (Prediction.py:396-427), same mirrored variance neighbourhood inside the window, so the
+    frames must agree bit for bit -- several batches with a ragged last one, with and without hipGraph replay, frame after frame; a frame
+    with more channels than its pass (not readable in place) falls back to the extraction path."""
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.prediction import Predictor
+    aj = configs.cfg2_unet_kpcn(filters=(16, 24, 32), convs=2)
+    H, W, T, O = 150, 230, 64, 10
+    key = Naming.feature_prediction_name("Emission")
+    g = torch.Generator().manual_seed(5)
+
+    def make_frame():
+        return {Naming.source_feature_name(f.name, index=0): (torch.randn(H, W, f.number_of_channels, generator=g).abs()
+                                                               * torch.exp(torch.randn(H, W, 1, generator=g))).cuda()
+                for f in arch.feature_predictions + arch.auxiliary_features}
+    arch = Architecture(aj, device="cuda", dtype=dtype, seed=4)
+    frames = [make_frame(), make_frame()]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DD_FRAME_INPUT", mode)
+        for use_graph in (False, True):
+            pred = Predictor(arch, tile_size=T, tile_overlap_size=O, tiles_per_batch=5, use_graph=use_graph)
+            got = [pred.predict_frame(fr)[key].clone() for fr in frames] + [pred.predict_frame(frames[0])[key].clone()]
+            torch.cuda.synchronize()
+            prog = pred._plans[(H, W)][1]
+            assert (prog.frame_input is not None) == (mode == "1")
+            outs[(mode, use_graph)] = got
+    ref = outs[("0", False)]
+    assert torch.isfinite(ref[0]).all() and not torch.equal(ref[0], ref[1]) and torch.equal(ref[0], ref[2])
+    for k, got in outs.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), k
+    # a frame wider than its pass: not readable in place
+    monkeypatch.setenv("DD_FRAME_INPUT", "1")
+    wide = dict(frames[0])
+    k0 = Naming.source_feature_name("Emission", index=0)
+    wide[k0] = torch.cat([wide[k0], torch.ones(H, W, 1, device="cuda")], dim=2)
+    pred = Predictor(arch, tile_size=T, tile_overlap_size=O, tiles_per_batch=5)
+    assert torch.equal(pred.predict_frame(wide)[key], ref[0])
+    assert pred._plans[(H, W)][1].frame_input is None
+
+
 def test_predictor_one_hot_flags_match_the_oracle():
     """ONE_HOT_ENCODING at inference: the constant one-hot planes the reference's prediction input_fn adds (Prediction.py:97-98,
     FeatureFlags.add_to_source_dictionary) are supplied by the Predictor itself."""
