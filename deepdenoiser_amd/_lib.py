@@ -16,7 +16,7 @@ MAX_FEATURES, MAX_COMBINED = 32, 8
 
 # every symbol include/dd_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    "dd_version", "dd_last_error", "dd_pack_weights", "dd_pack_weights_batched", "dd_conv_igemm", "dd_conv_wgrad", "dd_colsum",
+    "dd_version", "dd_last_error", "dd_pack_weights", "dd_pack_weights_batched", "dd_conv_igemm", "dd_conv_wgrad", "dd_colsum", "dd_colsum_segments",
     "dd_maxpool_fwd", "dd_maxpool_bwd", "dd_avgpool", "dd_prepare_feature", "dd_gather_input",
     "dd_kpcn_fwd", "dd_kpcn_bwd", "dd_kpcn_hidden_fwd", "dd_kpcn_hidden_bwd", "dd_compose_pack", "dd_compose_blend_fwd", "dd_compose_blend_bwd",
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
@@ -240,6 +240,7 @@ def load():
     lib.dd_wgrad_pw_count.argtypes = []
     lib.dd_wgrad_pw_count.restype = C.c_long
     lib.dd_colsum.argtypes = [vp, i, i, l, vp, i, vp]
+    lib.dd_colsum_segments.argtypes = [vp, i, i, l, i, vp, i, vp, i, vp]
     lib.dd_maxpool_fwd.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, i, i, vp]
     lib.dd_maxpool_bwd.argtypes = [vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.dd_avgpool.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]

@@ -181,6 +181,63 @@ template <> __device__ __forceinline__ void vstore<f16_t>(f16_t* p, const float 
 template <> __device__ __forceinline__ void vstore<float>(float* p, const float (&v)[4]) { store4<float>(p, v); }
 template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack8(v); }
 
+// Column sums of n_seg consecutive row segments in ONE launch: out[out_row[s]][ch] += sum over the rows of segment s.  The embedding-row
+// gradients of FeatureFlags.feature_flags (FeatureFlags.py:57-67: one row of the embedding matrix per tuple, tiled over the tuple's images) were
+// 17 dd_colsum launches of 8 channels each -- 8 live lanes of 64, 2-byte loads: 0.4 ms of the ArchitectureExample.json step; here a thread
+// loads 16-byte vectors (NV = vectors per row, a power of two <= 8), the lanes of a wave that hold the same vector are summed by xor-shuffles,
+// the four waves through LDS, and one set of atomics leaves per workgroup.
+struct ColsumSegP { const void* x; float* out; long rows; int ld, c, nv, out_ld; int out_row[64]; };
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_segments_kernel(const ColsumSegP p) {
+  constexpr int N = Elem<T>::PER16;
+  __shared__ float red[4][8 * N];
+  const int seg = blockIdx.y, nv = p.nv, v = threadIdx.x & (nv - 1);
+  const T* base = reinterpret_cast<const T*>(p.x) + (long)seg * p.rows * p.ld + v * N;
+  float s[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s[e] = 0.f;
+  const long rstep = (long)gridDim.x * (256 / nv);
+  for (long r = (long)blockIdx.x * (256 / nv) + threadIdx.x / nv; r < p.rows; r += rstep) {
+    float t[N];
+    vload<T>(base + r * p.ld, t);
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] += t[e];
+  }
+  for (int o = 32; o >= nv; o >>= 1)
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] += __shfl_xor(s[e], o);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane < nv)
+#pragma unroll
+    for (int e = 0; e < N; ++e) red[wv][lane * N + e] = s[e];
+  __syncthreads();
+  dd_det_wait();
+  if ((int)threadIdx.x < nv * N && (int)threadIdx.x < p.c)
+    atomicAdd(p.out + (long)p.out_row[seg] * p.out_ld + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  dd_det_end();
+}
+extern "C" int dd_colsum_segments(const void* x, int ld, int c, long rows_per_segment, int n_segments, float* out, int out_ld, const int* out_row,
+                                  int dtype, dd_stream stream) {
+  DD_REQUIRE(x && out && out_row && c > 0 && rows_per_segment > 0 && n_segments > 0 && n_segments <= 64 && out_ld >= c, "dd_colsum_segments: bad arguments");
+  DD_REQUIRE(dd_dtype_ok(dtype), "dd_colsum_segments: bad dtype %d", dtype);
+  const int per16 = dtype == DD_F32 ? 4 : 8, esz = dtype == DD_F32 ? 4 : 2;
+  int nv = 1;
+  while (nv * per16 < c) nv *= 2;
+  DD_REQUIRE(nv <= 8 && nv * per16 <= ld && ld % per16 == 0 && ((uintptr_t)x % 16) == 0 && (ld * esz) % 16 == 0,
+             "dd_colsum_segments: c=%d ld=%d (at most %d channels, rows of whole 16-byte vectors that cover them)", c, ld, 8 * per16);
+  ColsumSegP p;
+  p.x = x; p.out = out; p.rows = rows_per_segment; p.ld = ld; p.c = c; p.nv = nv; p.out_ld = out_ld;
+  for (int s = 0; s < n_segments; ++s) { DD_REQUIRE(out_row[s] >= 0, "dd_colsum_segments: negative output row"); p.out_row[s] = out_row[s]; }
+  long bx = (rows_per_segment + (256 / nv) * 8 - 1) / ((256 / nv) * 8);      // >= 8 rows per thread
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  dd_det_sync();
+  DD_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_segments_kernel<T>, dim3((unsigned)bx, (unsigned)n_segments), dim3(256), 0, S(stream), p));
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
                                    int C, int B, int H, int W, int OH, int OW, int pool, int stride, int pby, int pbx, int relu_mask) {
@@ -1547,23 +1604,28 @@ extern "C" int dd_adam_step(float* params, const float* grads, float* m, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ stitch
+// One workgroup = one row of one entry's crop window: cw * C contiguous floats on both sides (round 5: was one workgroup per entry walking its
+// ~100 x 100 x 3 elements with a 64-bit division each -- 209 workgroups, 61 us for the 66 MB of a 1080p frame).
 __global__ void stitch_kernel(const float* __restrict__ tiles, int ts, int ldt, float* __restrict__ frame, int fh, int fw, int ldf, int C,
                               const dd_stitch_entry* __restrict__ table) {
   const dd_stitch_entry e = table[blockIdx.x];
-  const int ch = e.crop_y1 - e.crop_y0, cw = e.crop_x1 - e.crop_x0;
-  const long total = (long)ch * cw * C;
-  for (long i = threadIdx.x; i < total; i += blockDim.x) {
-    const int c = (int)(i % C);
-    const long r = i / C;
-    const int x = (int)(r % cw), y = (int)(r / cw);
-    frame[(((long)e.dst_img * fh + e.dst_y + y) * fw + e.dst_x + x) * ldf + c] =
-        tiles[(((long)e.tile * ts + e.crop_y0 + y) * ts + e.crop_x0 + x) * ldt + c];
+  const int y = blockIdx.y, ch = e.crop_y1 - e.crop_y0, cw = e.crop_x1 - e.crop_x0;
+  if (y >= ch) return;
+  float* dst = frame + (((long)e.dst_img * fh + e.dst_y + y) * fw + e.dst_x) * ldf;
+  const float* src = tiles + (((long)e.tile * ts + e.crop_y0 + y) * ts + e.crop_x0) * ldt;
+  if (C == ldf && C == ldt) {
+    for (int i = threadIdx.x; i < cw * C; i += blockDim.x) dst[i] = src[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < cw * C; i += blockDim.x) {
+    const int x = i / C, c = i - x * C;
+    dst[(long)x * ldf + c] = src[(long)x * ldt + c];
   }
 }
 extern "C" int dd_stitch(const float* tiles, int tile_size, int ldt, float* frame, int frame_h, int frame_w, int ldf, int C,
                          const dd_stitch_entry* table, int n_entries, dd_stream stream) {
-  DD_REQUIRE(tiles && frame && table && n_entries > 0, "dd_stitch: bad arguments");
-  hipLaunchKernelGGL(stitch_kernel, dim3(n_entries), dim3(256), 0, S(stream), tiles, tile_size, ldt, frame, frame_h, frame_w, ldf, C, table);
+  DD_REQUIRE(tiles && frame && table && n_entries > 0 && tile_size > 0 && tile_size <= 65535, "dd_stitch: bad arguments");
+  hipLaunchKernelGGL(stitch_kernel, dim3(n_entries, tile_size), dim3(128), 0, S(stream), tiles, tile_size, ldt, frame, frame_h, frame_w, ldf, C, table);
   DD_LAUNCH_CHECK();
   return DD_OK;
 }

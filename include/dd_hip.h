@@ -181,6 +181,11 @@ int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream);
 
 /* column sums: out[c] += sum_rows x[row*ld + c]  (bias gradients; embedding-row gradients) */
 int dd_colsum(const void* x, int ld, int c, long rows, float* out, int dtype, dd_stream stream);
+/* the same over n_segments (<= 64) consecutive segments of rows_per_segment rows in one launch: out[out_row[s]*out_ld + ch] += the sum over
+ * segment s (the embedding-row gradients of FeatureFlags.feature_flags, FeatureFlags.py:57-67: one row per tuple, tiled over the tuple's images).
+ * out_row is a HOST table; c <= 8 16-byte vectors of the storage type (64 bf16 / fp16, 32 f32 channels), x 16-byte aligned, ld a multiple of a vector. */
+int dd_colsum_segments(const void* x, int ld, int c, long rows_per_segment, int n_segments, float* out, int out_ld, const int* out_row,
+                       int dtype, dd_stream stream);
 
 /* ---- max pooling, TF SAME (UNet.py:42-44 3x3/s2; Tiramisu.py:55-57 2x2/s2); idx = window argmax (uint8).
  * relu_mask != 0: x is a ReLU output whose backward mask (x > 0) is folded into idx (255 = the window maximum is not positive, no

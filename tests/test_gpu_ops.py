@@ -842,3 +842,34 @@ def test_compose_net_backward_streaming_op_level(dtype, shape):
     check("compose bwd d_fine", d_fine.double().cpu(), grads[1], tol)
     for n, gr in zip(names, grads[2:]):
         check("compose bwd d %s" % n, dws[n].double().cpu(), gr, tol)
+
+
+@pytest.mark.parametrize("dtype,c,ld,ch0", [("bf16", 8, 16, 8), ("f16", 8, 16, 8), ("f32", 8, 16, 8), ("bf16", 12, 32, 16), ("bf16", 64, 64, 0), ("f32", 5, 12, 4)])
+def test_colsum_segments_matches_the_per_tuple_column_sums(lib, dtype, c, ld, ch0):
+    """dd_colsum_segments (round 5): the embedding-row gradients of FeatureFlags.feature_flags (FeatureFlags.py:57-67) for every tuple in one launch,
+    against a float64 sum; rows land where the HOST table says (two segments sharing a row accumulate), channels outside [ch0, ch0 + c) are not read
+    into the result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from deepdenoiser_amd import _lib as L
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+    code = {"f32": L.DD_F32, "bf16": L.DD_BF16, "f16": L.DD_F16}[dtype]
+    nseg, rows = 5, 3001
+    x = torch.randn(nseg * rows, ld, generator=_gen(7)).to(tdt).cuda()
+    out_row = [3, 0, 3, 6, 1]
+    out = torch.zeros(8, c + 3, dtype=torch.float32).cuda()
+    out[:, c:] = 7.0
+    tab = (ctypes.c_int * nseg)(*out_row)
+    esz = x.element_size()
+    rc = lib.dd_colsum_segments(x.data_ptr() + ch0 * esz, ld, c, rows, nseg, out.data_ptr(), c + 3, tab, code, None)
+    assert rc == 0, lib.dd_last_error()
+    torch.cuda.synchronize()
+    want = torch.zeros(8, c, dtype=torch.float64)
+    xs = x.cpu().double().reshape(nseg, rows, ld)[:, :, ch0:ch0 + c].sum(1)
+    for s, r in enumerate(out_row):
+        want[r] += xs[s]
+    got = out.cpu().double()
+    assert torch.all(got[:, c:] == 7.0)
+    assert float((got[:, :c] - want).abs().max()) < 1e-3 * float(want.abs().max())
+    # arguments it cannot take are refused, not mis-summed
+    assert lib.dd_colsum_segments(x.data_ptr() + 2, ld, c, rows, nseg, out.data_ptr(), c + 3, tab, code, None) != 0
