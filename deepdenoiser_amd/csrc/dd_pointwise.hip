@@ -1536,6 +1536,161 @@ __global__ __launch_bounds__(256) void loss_simple_kernel(const LossSimpleP P) {
   dd_det_end();
 }
 
+// Mean-only descriptors with combined / image terms (TrainingExample.json: feature x 1, combined x 5, image x 10; no variation term): one thread
+// per pixel as in loss_head_kernel, but the pixel's predictions, targets and gradients of ALL features live in the thread's own LDS column
+// ([feature][p0 p1 p2 t0 t1 t2 g0 g1 g2][lane]) -- every global value is read once (the loads of all features are in flight together) and every
+// gradient written once.  loss_head_kernel re-read a feature per term and accumulated the combined / image gradients with global read-modify-
+// writes: ~300 dependent memory operations per thread, 66 us even for the 8 192 pixels of the coarsest scale.  Same terms in the same order,
+// so dpred is bit-identical to loss_head_kernel's.  The inverse standardization fuses exactly as in loss_simple_kernel.
+__device__ __forceinline__ float invert_fwd(float x, float mean, float std, int log1p, float& dinv) {
+  float z = x * std + mean;
+  dinv = std;
+  if (log1p) {
+    dinv *= (z != 0.f) ? expf(fabsf(z)) : 0.f;
+    z = z > 0.f ? expm1f(z) : (z < 0.f ? -expm1f(-z) : 0.f);
+  }
+  return z;
+}
+__global__ __launch_bounds__(64) void loss_general_kernel(const dd_loss_desc d, long npix, float inv_count, float grad_scale, float* __restrict__ loss_out) {
+  extern __shared__ float lg_sm[];                       // [n_features][9][64]
+  const int lane = threadIdx.x;
+  float loss = 0.f;
+  auto P = [&](int f, int c) -> float& { return lg_sm[(f * 9 + c) * 64 + lane]; };
+  auto Tg = [&](int f, int c) -> float& { return lg_sm[(f * 9 + 3 + c) * 64 + lane]; };
+  auto G = [&](int f, int c) -> float& { return lg_sm[(f * 9 + 6 + c) * 64 + lane]; };
+  // mean term of one source: adds to `loss`, returns dLoss/dvalue
+  auto term = [&](const float (&p)[3], const float (&t)[3], int nch, float w, float (&g)[3]) {
+    g[0] = g[1] = g[2] = 0.f;
+    if (w == 0.f) return;
+    for (int ch = 0; ch < nch; ++ch) {
+      float l, dl;
+      loss_term(d.kind, d.epsilon, p[ch], t[ch], &l, &dl);
+      loss += w * l;
+      g[ch] += w * dl * grad_scale;
+    }
+  };
+  auto masked_w = [&](float w, int mask_f, int src) -> float {      // masked_pixel_weight with the mask feature's target taken from LDS
+    if (w == 0.f || mask_f < 0 || d.mask_sums == nullptr) return 0.f;
+    const float msum = d.mask_sums[src];
+    float sa = 0.f;
+    for (int c = 0; c < d.nch[mask_f]; ++c) sa += fabsf(Tg(mask_f, c));
+    return msum > 0.f ? w * (sa > 0.f ? 1.f : 0.f) / msum : 0.f;
+  };
+  auto comb_val = [&](int k, float (&p)[3], float (&t)[3]) {
+    const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p[c] = P(fc, c) * (P(fd, c) + P(fi, c)); t[c] = Tg(fc, c) * (Tg(fd, c) + Tg(fi, c)); }
+  };
+  for (long i0 = (long)blockIdx.x * 64; i0 < npix; i0 += (long)gridDim.x * 64) {
+    const long i = i0 + lane;
+    const bool live = i < npix;
+    const long ii = live ? i : npix - 1;
+    // every feature's prediction and target of this pixel -> LDS (1-channel passes broadcast channel 0, Training.py:422-426); the loads of FB
+    // features are requested before the first one is used (a thread has one wave per SIMD around it: 39 KiB of LDS per 64 pixels at 17 features)
+    constexpr int FB = 4;
+    for (int f0 = 0; f0 < d.n_features; f0 += FB) {
+      float pv[FB][3], tv[FB][3];
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int f = min(f0 + u, d.n_features - 1);
+        const bool one = d.nch[f] == 1, fused = d.pred_std[f] != nullptr;
+        const float* pp = fused ? d.pred_std[f] + ii * 3 : d.pred[f] + ii * d.pred_ld[f];
+        const float* tp = d.target[f] + ii * d.target_ld[f];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pv[u][c] = pp[(one && !fused) ? 0 : c]; tv[u][c] = tp[one ? 0 : c]; }
+      }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int f = f0 + u;
+        if (f >= d.n_features) break;
+        if (d.pred_std[f]) {
+          float dinv;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) pv[u][c] = invert_fwd(pv[u][c], d.inv_mean[f], d.inv_std[f], d.inv_log1p[f], dinv);
+          if (live) { float* po = d.pred_inv[f] + ii * 3; po[0] = pv[u][0]; po[1] = pv[u][1]; po[2] = pv[u][2]; }
+          if (d.nch[f] == 1) pv[u][1] = pv[u][2] = pv[u][0];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { P(f, c) = pv[u][c]; Tg(f, c) = tv[u][c]; }
+      }
+    }
+    if (live) {
+      for (int f = 0; f < d.n_features; ++f) {
+        const float pv[3] = {P(f, 0), P(f, 1), P(f, 2)}, tv[3] = {Tg(f, 0), Tg(f, 1), Tg(f, 2)};
+        float g[3];
+        term(pv, tv, d.nch[f], d.weight[f] * inv_count + masked_w(d.masked_weight[f], d.mask_feature[f], f), g);
+        G(f, 0) = g[0]; G(f, 1) = g[1]; G(f, 2) = g[2];
+      }
+      if (d.n_combined > 0 || d.n_image_features > 0) {
+        float dimg[3] = {0.f, 0.f, 0.f};
+        const bool use_image = (d.image_weight != 0.f || d.image_var_weight != 0.f) && (d.n_image_combined > 0 || d.n_image_features > 0);
+        if (use_image) {
+          float pv[3] = {0.f, 0.f, 0.f}, tv[3] = {0.f, 0.f, 0.f};
+          for (int j = 0; j < d.n_image_combined; ++j) {
+            float a[3], b[3];
+            comb_val(d.image_combined[j], a, b);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pv[c] += a[c]; tv[c] += b[c]; }
+          }
+          for (int j = 0; j < d.n_image_features; ++j) {
+            const int f = d.image_features[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pv[c] += P(f, c); tv[c] += Tg(f, c); }
+          }
+          term(pv, tv, 3, d.image_weight * inv_count, dimg);
+          for (int j = 0; j < d.n_image_features; ++j) {
+            const int f = d.image_features[j];
+            for (int c = 0; c < 3; ++c) G(f, d.nch[f] == 1 ? 0 : c) += dimg[c];
+          }
+        }
+        for (int k = 0; k < d.n_combined; ++k) {
+          const int fc = d.comb[k][0], fd = d.comb[k][1], fi = d.comb[k][2];
+          bool in_image = false;
+          for (int j = 0; j < d.n_image_combined; ++j) in_image |= (d.image_combined[j] == k);
+          float pv[3], tv[3], g[3];
+          comb_val(k, pv, tv);
+          term(pv, tv, 3, d.comb_weight[k] * inv_count + masked_w(d.comb_masked_weight[k], d.comb_mask_feature[k], DD_MAX_FEATURES + k), g);
+          for (int ch = 0; ch < 3; ++ch) {
+            const float gt = g[ch] + ((use_image && in_image) ? dimg[ch] : 0.f);
+            const int cc = d.nch[fc] == 1 ? 0 : ch, cd = d.nch[fd] == 1 ? 0 : ch, ci = d.nch[fi] == 1 ? 0 : ch;
+            const float pc = P(fc, ch);
+            G(fc, cc) += gt * (P(fd, ch) + P(fi, ch));
+            G(fd, cd) += gt * pc;
+            G(fi, ci) += gt * pc;
+          }
+        }
+      }
+      // dL/dp, or -- fused -- dL/dx = dL/dp . dp/dx with the chain factor of invert_std_bwd_kernel recomputed from x (L2 hits, FB features at a time)
+      for (int f0 = 0; f0 < d.n_features; f0 += FB) {
+        float xv[FB][3];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+          const int f = min(f0 + u, d.n_features - 1);
+          const float* xp = d.pred_std[f] ? d.pred_std[f] + i * 3 : d.target[f] + i * d.target_ld[f];      // (unfused: any valid address, unused)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xv[u][c] = xp[d.pred_std[f] ? c : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+          const int f = f0 + u;
+          if (f >= d.n_features) break;
+          float* dp = d.dpred[f] + i * 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float dinv = 1.f;
+            if (d.pred_std[f]) (void)invert_fwd(xv[u][c], d.inv_mean[f], d.inv_std[f], d.inv_log1p[f], dinv);
+            dp[c] = G(f, c) * dinv;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+  if (lane == 0) { dd_det_wait(); atomicAdd(loss_out, loss); }
+  dd_det_end();
+}
+
 extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float* loss_out, float grad_scale, dd_stream stream) {
   DD_REQUIRE(desc && loss_out && desc->n_features > 0 && desc->n_features <= DD_MAX_FEATURES && desc->n_combined <= DD_MAX_COMBINED,
              "dd_loss_head: bad descriptor");
@@ -1555,8 +1710,12 @@ extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float
     if (desc->pred_std[f]) DD_REQUIRE(desc->pred_inv[f] && desc->inv_std[f] > 0.f, "dd_loss_head: pred_std[%d] needs pred_inv and a positive inv_std", f);
   }
   static const bool simple_on = [] { const char* e = getenv("DD_LOSS_SIMPLE"); return !(e && e[0] == '0'); }();
-  DD_REQUIRE(!fused_any || simple, "dd_loss_head: the fused inverse standardization (pred_std) needs a features-only descriptor "
-             "(no combined / image / variation / masked terms, 3-float pixels, 16-byte aligned blocks)");
+  // no variation term anywhere: every term is a function of ONE pixel (loss_general_kernel; DD_LOSS_GENERAL=0: the older kernel)
+  bool pixel_local = desc->image_var_weight == 0.f;
+  for (int f = 0; f < desc->n_features; ++f) pixel_local = pixel_local && desc->var_weight[f] == 0.f;
+  for (int k = 0; k < desc->n_combined; ++k) pixel_local = pixel_local && desc->comb_var_weight[k] == 0.f;
+  static const bool general_on = [] { const char* e = getenv("DD_LOSS_GENERAL"); return !(e && e[0] == '0'); }();
+  DD_REQUIRE(!fused_any || simple || pixel_local, "dd_loss_head: the fused inverse standardization (pred_std) needs a descriptor without variation terms");
   if (simple && (simple_on || fused_any)) {
     LossSimpleP P;
     memset(&P, 0, sizeof(P));
@@ -1574,6 +1733,15 @@ extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float
     dd_det_sync();
     const long want = (P.nvec + 511) / 512;
     hipLaunchKernelGGL(loss_simple_kernel, dim3((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048)), dim3(256), 0, S(stream), P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+  }
+  if (pixel_local && (general_on || fused_any)) {
+    const size_t lds = (size_t)desc->n_features * 9 * 64 * sizeof(float);
+    dd_allow_max_lds(reinterpret_cast<const void*>(loss_general_kernel), 96 * 1024);
+    dd_det_sync();
+    const long want = (npix + 63) / 64;
+    hipLaunchKernelGGL(loss_general_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(64), lds, S(stream), *desc, npix, 1.f / (float)npix, grad_scale, loss_out);
     DD_LAUNCH_CHECK();
     return DD_OK;
   }

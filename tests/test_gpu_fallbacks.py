@@ -24,6 +24,10 @@ CASES = {   # name: (environment of the child, -k expression[, test file (defaul
     # ... and the 16 x 16-tile compose kernels of round 2 / 3 (csrc/dd_compose.hip) in place of the row-streaming ones, forward and backward
     "tile_compose_kernels": ({"DD_COMPOSE_STREAM": "0", "DD_COMPOSE_STREAM_BWD": "0"},
                              "test_fused_compose_net_matches_the_layerwise_path", "test_gpu_round2.py"),
+    # round 5: the loss launch before its per-pixel kernels (one thread re-reading features per term, global read-modify-write gradients) and with
+    # the inverse standardization as launches of its own -- the path that still carries the variation terms
+    "older_loss_kernel_unfused": ({"DD_LOSS_SIMPLE": "0", "DD_LOSS_GENERAL": "0", "DD_FUSE_LOSS_INVERT": "0"},
+                                  "(test_training_step_parity_f32 and (example_json or cfg2)) or test_masked_mean", "test_gpu_model.py"),
     "tile_compose_kernels_bit_faithful": ({"DD_COMPOSE_STREAM": "0", "DD_COMPOSE_STREAM_BWD": "0"},
                                           "test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful", "test_gpu_round3.py"),
 }
