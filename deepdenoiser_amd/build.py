@@ -61,7 +61,7 @@ def check_async_loads(asm, request, wait):
     pending, groups, fn = {}, 0, "?"
     for ln, line in enumerate(asm.splitlines(), 1):
         code = line.split(";", 1)[0].strip()
-        if line and not line[0].isspace() and line.rstrip().endswith(":") and not line.startswith("."):
+        if line and not line[0].isspace() and line.rstrip().endswith(":") and not line.startswith(".") and not line.startswith(";"):
             fn = line.rstrip()[:-1]
             if pending:
                 raise RuntimeError("%s: request at line %d never reached its wait" % (fn, min(pending.values())))
@@ -69,9 +69,11 @@ def check_async_loads(asm, request, wait):
             dst = code.split(None, 1)[1].split(",", 1)[0]
             if not pending:
                 groups += 1
+            # its address operand must not be the destination of an EARLIER request (its own destination may overlap it: the address is read
+            # when the instruction issues)
+            hit = _vregs(code.split(",", 1)[1]) & set(pending)
             for r in _vregs(dst):
                 pending[r] = ln
-            hit = _vregs(code.split(",", 1)[1]) & set(pending)          # its own address operand must not be a pending destination either
         elif wait in line:
             pending = {}
             continue

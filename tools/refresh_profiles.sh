@@ -46,5 +46,12 @@ HSA_ENABLE_IPC_MODE_LEGACY=0 DD_FORCE_COLLECTIVES=1 timeout 600 python -m torch.
 tools/pmc_sq_table.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_table.txt $out/sq_table.txt
 ( for v in hip nodma0 nowrole noflush0; do echo "== $v"; if [ $v = hip ]; then python tools/wgrad_only_bench.py 2>/dev/null; elif [ -f tools/exp/libdd_$v.so ]; then DD_LIB=tools/exp/libdd_$v.so python tools/wgrad_only_bench.py 2>/dev/null; fi; done ) > $out/wgrad_only_knockouts.txt 2>&1
 ( DD_DETERMINISTIC=1 python tools/det_diag.py cfg2; python tools/det_diag.py cfg2 ) > $out/deterministic.txt 2>&1
+# round 5, second half: the literal ArchitectureExample.json step by family, the A/B pairs DESIGN 7.5 cites (one process per variant, same box)
+python tools/example_profile.py 8 > $out/example_profile.txt 2>&1
+( timeout 600 python tools/ab_bench.py "default:" "loss_unfused:DD_FUSE_LOSS_INVERT=0,DD_LOSS_SIMPLE=0,DD_LOSS_GENERAL=0" --repeat 2;
+  timeout 600 python tools/ab_bench.py "frames_in_place:" "extract_tiles:DD_FRAME_INPUT=0" --inference --repeat 2 ) > $out/ab_round5.txt 2>&1
+[ -f tools/exp/libdd_natpitch.so ] && ( timeout 400 python tools/ab_bench.py "padded_strips:" "natural_pitch:DD_LIB=tools/exp/libdd_natpitch.so" --repeat 2 ) >> $out/ab_round5.txt 2>&1
+python tools/cfg3_launches.py light 8 > $out/cfg3_light_launches.txt 2>&1
+python tools/cfg3_launches.py heavy 8 > $out/cfg3_heavy_launches.txt 2>&1
 rm -rf $out/prof $out/prof_inf $out/prof_cfg3 $out/prof_cfg3l $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 cat $out/smoke.txt | tail -2; cut -c1-300 $out/bench.json; cat $out/pmc_*.txt; head -12 $out/kernel_stats.txt
