@@ -60,7 +60,9 @@ class WgradArgs(C.Structure):
                 ("q", C.c_void_p), ("ldq", C.c_int), ("n", C.c_int),
                 ("out", C.c_void_p), ("bias_out", C.c_void_p), ("bias_mode", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("taps", C.c_int), ("flags", C.c_int), ("dtype", C.c_int), ("ksplit", C.c_int)]
+                ("taps", C.c_int), ("flags", C.c_int), ("dtype", C.c_int), ("ksplit", C.c_int),
+                ("stack_blocks", C.c_int), ("stack_width", C.c_int), ("stack_m0", C.c_int),
+                ("stack_out", C.c_void_p * 8), ("stack_bias", C.c_void_p * 8)]
 
 
 class ConvBwdArgs(C.Structure):

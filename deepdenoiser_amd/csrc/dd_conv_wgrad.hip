@@ -51,6 +51,9 @@ struct WgradP {
   int tiles_x, tiles_y, ksplit, mslices, nslices;
   int ncombo, cstart[65];       // LDS-DMA kernel: workgroups [cstart[c], cstart[c+1]) split the pixel tiles of (ms, ns) = (c / nslices, c % nslices)
   int hin, win;
+  // stacked form (dd_wgrad_args): column block n / stack_width of the product belongs to conv j = that block, rows below stack_m0 + j * stack_width
+  int stack_blocks, stack_width, stack_m0;
+  float* stack_out[8]; float* stack_bias[8];
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
@@ -641,10 +644,15 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
     for (int j = 0; j < NPW; ++j) {
       const int n = ns * KC + (nj + j) * 16 + li;
       if (n >= a.n) continue;
+      // stacked form: this column belongs to conv jb of the dense block; only the rows of ITS input prefix are its gradient
+      const int jb = a.stack_blocks ? n / a.stack_width : 0;
+      const int mlim = a.stack_blocks ? a.stack_m0 + jb * a.stack_width : a.m;
+      const int ncols = a.stack_blocks ? a.stack_width : a.n, nn = a.stack_blocks ? n - jb * a.stack_width : n;
+      float* outp = a.stack_blocks ? a.stack_out[jb] : a.out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = ms * KC + mi * 16 + q4 + e;
-        if (m < a.m) atomicAdd(a.out + ((long)t * a.m + m) * a.n + n, acc[i][j][e]);
+        if (m < mlim) atomicAdd(outp + ((long)t * mlim + m) * ncols + nn, acc[i][j][e]);
       }
     }
   }
@@ -655,7 +663,10 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradP a) {
       b += __shfl_xor(b, 16);
       b += __shfl_xor(b, 32);
       const int c = ns * KC + (nj + jj) * 16 + li;
-      if (bias_wave && lane < 16 && c < a.n) atomicAdd(a.bias_out + c, b);
+      if (bias_wave && lane < 16 && c < a.n) {
+        if (a.stack_blocks) atomicAdd(a.stack_bias[c / a.stack_width] + c % a.stack_width, b);
+        else atomicAdd(a.bias_out + c, b);
+      }
     }
   }
   WPHASE_T(e1);
@@ -735,6 +746,7 @@ int dispatch(const WgradP& p, hipStream_t stream) {
       return launch_dma<T>(q, stream);
     }
   }
+  if (p.stack_blocks) { dd_set_error("dd_conv_wgrad: the stacked form runs on the LDS-DMA kernel only (2-byte storage, <= 64 channel-slice pairs, DD_WGRAD_DMA on)"); return DD_ERR_INVALID; }
   switch (p.taps) {
     case 9: return launch<T, 9>(p, stream);
     case 4: return launch<T, 4>(p, stream);
@@ -748,7 +760,14 @@ bool dd_wgrad_pw_eligible(const dd_wgrad_args* a);
 int dd_wgrad_pw_launch(const dd_wgrad_args* a, hipStream_t stream);
 
 extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
-  DD_REQUIRE(a && a->p && a->q && a->out, "dd_conv_wgrad: null pointer");
+  DD_REQUIRE(a && a->p && a->q && (a->out || a->stack_blocks > 0), "dd_conv_wgrad: null pointer");
+  if (a->stack_blocks != 0) {
+    DD_REQUIRE(a->stack_blocks > 0 && a->stack_blocks <= 8 && a->stack_width > 0 && a->stack_m0 > 0 && a->taps == 9 && a->dtype != DD_F32 && !(a->flags & DD_GATHER2X2)
+               && a->n == a->stack_blocks * a->stack_width && a->m == a->stack_m0 + (a->stack_blocks - 1) * a->stack_width && a->bias_mode != 2,
+               "dd_conv_wgrad: stacked form: taps = 9, 2-byte storage, n = stack_blocks * stack_width, m = stack_m0 + (stack_blocks - 1) * stack_width");
+    for (int j = 0; j < a->stack_blocks; ++j)
+      DD_REQUIRE(a->stack_out[j] && (a->bias_mode == 0 || a->stack_bias[j]), "dd_conv_wgrad: stacked form: block %d has no output pointer", j);
+  }
   DD_REQUIRE(dd_dtype_ok(a->dtype), "dd_conv_wgrad: bad dtype %d", a->dtype);
   const int esz = a->dtype == DD_F32 ? 4 : 2, per16 = 16 / esz, kc = DD_LDS_ROW / esz;
   const bool gather = (a->flags & DD_GATHER2X2) != 0;
@@ -759,10 +778,12 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
              "dd_conv_wgrad: m=%d n=%d ldp=%d ldq=%d: ld must be a multiple of %d and cover the rounded channel count", a->m, a->n, a->ldp, a->ldq, per16);
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "dd_conv_wgrad: empty grid");
   DD_REQUIRE(((uintptr_t)a->p % 16) == 0 && ((uintptr_t)a->q % 16) == 0, "dd_conv_wgrad: pointers must be 16-byte aligned");
-  DD_REQUIRE(a->bias_mode >= 0 && a->bias_mode <= 2 && (a->bias_mode == 0 || a->bias_out), "dd_conv_wgrad: bias_mode=%d needs bias_out", a->bias_mode);
+  DD_REQUIRE(a->bias_mode >= 0 && a->bias_mode <= 2 && (a->bias_mode == 0 || a->bias_out || a->stack_blocks > 0), "dd_conv_wgrad: bias_mode=%d needs bias_out", a->bias_mode);
   // wide 1x1 layers: the gradient as 256 x 256 GEMM tiles over the linear pixel index (csrc/dd_conv_pw.hip)
   if (dd_wgrad_pw_eligible(a)) return dd_wgrad_pw_launch(a, reinterpret_cast<hipStream_t>(stream));
   WgradP p;
+  p.stack_blocks = a->stack_blocks; p.stack_width = a->stack_width; p.stack_m0 = a->stack_m0;
+  for (int j = 0; j < 8; ++j) { p.stack_out[j] = j < a->stack_blocks ? a->stack_out[j] : nullptr; p.stack_bias[j] = j < a->stack_blocks ? a->stack_bias[j] : nullptr; }
   p.p = a->p; p.q = a->q; p.out = a->out; p.bias_out = a->bias_out; p.bias_mode = a->bias_mode;
   p.ldp = a->ldp; p.m = a->m; p.ldq = a->ldq; p.n = a->n; p.mv = mv; p.nv = nv;
   p.B = a->B; p.H = a->H; p.W = a->W; p.taps = a->taps; p.flags = a->flags;

@@ -326,6 +326,32 @@ class Graph:
         run.info = self.wgrad_records[-1]
         return run
 
+    def _wgrad_stack_call(self, p, q, layers, m0, width, B, H, W, flags):
+        """The weight / bias gradients of every conv of a dense block in ONE launch (dd_conv_wgrad, stacked form): p = the longest input prefix,
+        q = the contiguous output gradients of all its convs."""
+        ps, nb = self.params, len(layers)
+        m, n = m0 + (nb - 1) * width, nb * width
+        flops = sum(2.0 * B * H * W * 9 * (m0 + j * width) * width for j in range(nb))
+        self.wgrad_records.append({"flops": flops, "B": B, "H": H, "W": W, "taps": 9, "m": m, "n": n, "stacked": nb})
+        rec = self.wgrad_records[-1]
+        a = L.WgradArgs()
+        a.p, a.ldp, a.m = p.ptr, p.ld, m
+        a.q, a.ldq, a.n = q.ptr, q.ld, n
+        a.out, a.bias_out, a.bias_mode = None, None, 1
+        a.B, a.H, a.W, a.taps, a.flags, a.dtype, a.ksplit = B, H, W, 9, flags, self.code, 0
+        a.stack_blocks, a.stack_width, a.stack_m0 = nb, width, m0
+        lib = self.lib
+        keep = (p.buf, q.buf)
+
+        def run(stream, a=a, keep=keep, bound=[]):
+            if not bound:      # parameter pointers exist only after ParamStore.finalize()
+                for j, lay in enumerate(layers):
+                    a.stack_out[j], a.stack_bias[j] = ps.grad_ptr(lay.kernel), ps.grad_ptr(lay.bias)
+                bound.append(1)
+            L.check(lib.dd_conv_wgrad(C.byref(a), stream))
+        run.info, run.tag = rec, "conv_wgrad"
+        return run
+
     def _conv_bwd_call(self, gy, x, layer, wd, n_pad, k_pad, gx, use_mask, accumulate, as_wgrad=False):
         """Data + weight + bias gradients of a 3x3 layer in one launch (csrc/dd_conv_bwd.hip); gx None: weight / bias gradients only
         (as_wgrad: accounted with the weight-gradient launches)."""
@@ -427,7 +453,11 @@ class Graph:
             self.fwd(self._defer(lambda: self._conv_call(xb, wb, taps, n_pad, kb_pad, None, 0, part, None, y,
                                                          x.B, x.H, x.W, flags, nk=(layer.cout, layer.cin - split_at)), "conv_igemm"))
         elif (self.dtype in ("bf16", "f16") and layer.k == 3 and res is None and (in_relu or layer.cin > 128) and layer.cout % 4 == 0 and layer.cout <= 256
-              and x.ld % 8 == 0 and y.ld % 4 == 0 and x.ch0 % 8 == 0 and y.ch0 % 4 == 0 and os.environ.get("DD_CONV_KS", "1") != "0"):
+              and x.ld % 8 == 0 and y.ld % 4 == 0 and x.ch0 % 8 == 0 and y.ch0 % 4 == 0 and os.environ.get("DD_CONV_KS", "1") != "0"
+              # thin layers over a short reduction (<= 32 new channels from <= 144: the 256 x 256 level of the light Tiramisu) keep their whole weight
+              # image in LDS on dd_conv_igemm: measured per layer (round 5, B = 8 at 256 x 256) 47 - 64 us against 73 - 95 us K-streamed, where all
+              # eight waves of a workgroup re-load the same 18 weight fragments per 64-channel slice (DD_CONV_KS_THIN=1 streams them anyway)
+              and not (layer.cout <= 32 and layer.cin <= 144 and os.environ.get("DD_CONV_KS_THIN", "0") != "1")):
             # Tiramisu's dense-block convs (pre-activation, reduction over the growing concat: K = 9 x up to 1 088 channels, 16 ... 128 new
             # channels): both operands streamed per 64-channel K-slice (csrc/dd_conv_ks.hip); the LDS-weight kernel can keep none of it resident
             wp, taps, n_pad, k_pad = layer.packed("fwd")
@@ -565,13 +595,23 @@ class Graph:
                 dense_gather.tag, dense_gather.info = "conv_igemm", rec
                 self.bwd(dense_gather)
 
+            # Round 5: the weight gradients of the block's convs are ONE launch behind the gathers (their output gradients are one contiguous
+            # channel range, their inputs nested prefixes: dd_conv_wgrad's stacked form).  With 16 ... 32 new channels per conv a launch of its own
+            # filled a quarter of the kernel's 64-channel slices and four of its eight waves: 95 - 125 us each for ~10 us of HBM traffic.
+            stack = (1 < n <= 8 and os.environ.get("DD_WGRAD_STACK", "1") != "0" and os.environ.get("DD_WGRAD_DMA", "1") != "0"
+                     and -(-(c0 + (n - 1) * f) // 64) * -(-(n * f) // 64) <= 64)
             for j in reversed(range(n)):
                 lay, cj = layers[j], c0 + j * f
                 if j < n - 1:
                     gather_call(*plans[j])
+                if stack:
+                    continue
                 x, gy = buf.view(0, cj), gbuf.view(cj, f)
                 self.bwd(self._defer(lambda x=x, gy=gy, lay=lay: self._wgrad_call(x, lay.cin, gy, lay.cout, ps.grad_ptr(lay.kernel), x.B, x.H, x.W, 9, L.IN_RELU,
                                                                                    ps.grad_ptr(lay.bias), 1), "conv_wgrad"), grad_params=[lay.kernel, lay.bias])
+            if stack:
+                self.bwd(self._wgrad_stack_call(buf.view(0, c0 + (n - 1) * f), gbuf.view(c0, n * f), layers, c0, f, buf.B, buf.H, buf.W, L.IN_RELU),
+                         "conv_wgrad", grad_params=[p_ for lay in layers for p_ in (lay.kernel, lay.bias)])
             if buf.requires_grad and c0 > 0:
                 gather_call(*plans[n - 1])
             buf.mark_grad_written()

@@ -97,6 +97,14 @@ typedef struct {
   int B, H, W;                         /* grid of Q (the reduction pixels) */
   int taps; int flags; int dtype;
   int ksplit;                          /* number of reduction splits (0 = choose) */
+  /* Stacked form (round 5; taps = 9, 2-byte storage): the weight gradients of ALL convs of a Tiramisu dense block (Tiramisu.py:26-41) in one
+   * launch.  Conv j reads the prefix [0, stack_m0 + j * stack_width) of the block's buffer and appends stack_width channels, so the output
+   * gradients of the stack_blocks convs are ONE contiguous channel range: Q = that range (n = stack_blocks * stack_width), P = the longest
+   * prefix (m = stack_m0 + (stack_blocks - 1) * stack_width).  Column block j of the product, rows below its conv's own input width, is conv j's
+   * gradient: stack_out[j] [taps][stack_m0 + j * stack_width][stack_width] and, with bias_mode = 1, stack_bias[j] [stack_width] (fp32 atomics);
+   * out / bias_out are not used.  stack_blocks = 0: the plain form above. */
+  int stack_blocks; int stack_width; int stack_m0;
+  float* stack_out[8]; float* stack_bias[8];
 } dd_wgrad_args;
 int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream);
 

@@ -103,8 +103,17 @@ KS_CASES = [
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,H,W,B", KS_CASES)
-def test_conv_k_streamed_dense_block_layers(eng, dtype, cin, cout, H, W, B):
+def test_conv_k_streamed_dense_block_layers(eng, dtype, cin, cout, H, W, B, monkeypatch):
+    monkeypatch.setenv("DD_CONV_KS_THIN", "1")      # (thin layers over a short reduction default to dd_conv_igemm since round 5: next test)
     _conv_case(eng, dtype, 3, cin, cout, H, W, False, True, False, False, B=B, expect_fwd_tag="ks_fwd")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(144, 16, 40, 24, 1), (16, 16, 35, 18, 2), (136, 24, 24, 8, 2), (96, 32, 16, 16, 2)])
+def test_thin_pre_activation_layers_run_on_the_lds_weight_kernel(eng, dtype, cin, cout, H, W, B):
+    """<= 32 new channels from <= 144 (the 256 x 256 level of the light Tiramisu, Tiramisu.py:26-41): the whole weight image stays in LDS on
+    dd_conv_igemm (round 5: 47 - 64 us against 73 - 95 us K-streamed at B = 8, 256 x 256); same gates as every conv."""
+    _conv_case(eng, dtype, 3, cin, cout, H, W, False, True, False, False, B=B)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -873,3 +882,57 @@ def test_colsum_segments_matches_the_per_tuple_column_sums(lib, dtype, c, ld, ch
     assert float((got[:, :c] - want).abs().max()) < 1e-3 * float(want.abs().max())
     # arguments it cannot take are refused, not mis-summed
     assert lib.dd_colsum_segments(x.data_ptr() + 2, ld, c, rows, nseg, out.data_ptr(), c + 3, tab, code, None) != 0
+
+
+@pytest.mark.parametrize("dtype,m0,width,nb,H,W,B", [("bf16", 16, 16, 4, 20, 28, 2), ("f16", 40, 24, 4, 16, 16, 1), ("bf16", 64, 32, 2, 17, 33, 2), ("bf16", 24, 8, 3, 16, 16, 1)])
+def test_stacked_weight_gradients_of_a_dense_block_match_one_launch_per_conv(lib, dtype, m0, width, nb, H, W, B):
+    """dd_conv_wgrad, stacked form (round 5): the Conv2DBackpropFilter / BiasAddGrad ops of ALL convs of a Tiramisu dense block (Tiramisu.py:26-41
+    behind Training.py:701-702) from one pass over the longest prefix and the contiguous output gradients, against one plain launch per conv
+    (fp32 atomics either way: summation order differs, ACC32) and against a float64 correlation for the first block."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from deepdenoiser_amd import _lib as L
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    code = L.DD_BF16 if dtype == "bf16" else L.DD_F16
+    m, n = m0 + (nb - 1) * width, nb * width
+    ld = ((m + n + 15) // 8) * 8
+    g = _gen(21)
+    buf = representable(torch.randn(B, H, W, ld, generator=g, dtype=torch.float64), dtype).to(tdt).cuda()      # [prefix | conv outputs], pre-activation
+    grad = torch.zeros(B, H, W, ld, dtype=tdt).cuda()
+    grad[..., m0:m0 + n] = representable(torch.randn(B, H, W, n, generator=g, dtype=torch.float64), dtype).to(tdt).cuda()
+    esz = 2
+
+    def call(stack, j=0):
+        a = L.WgradArgs()
+        a.p, a.ldp, a.q, a.ldq = buf.data_ptr(), ld, grad.data_ptr() + (m0 + (0 if stack else j * width)) * esz, ld
+        a.B, a.H, a.W, a.taps, a.flags, a.dtype, a.ksplit, a.bias_mode = B, H, W, 9, L.IN_RELU, code, 0, 1
+        if stack:
+            outs = [torch.zeros(9, m0 + i * width, width).cuda() for i in range(nb)]
+            bs = [torch.zeros(width).cuda() for _ in range(nb)]
+            a.m, a.n, a.stack_blocks, a.stack_width, a.stack_m0 = m, n, nb, width, m0
+            for i in range(nb):
+                a.stack_out[i], a.stack_bias[i] = outs[i].data_ptr(), bs[i].data_ptr()
+        else:
+            outs, bs = [torch.zeros(9, m0 + j * width, width).cuda()], [torch.zeros(width).cuda()]
+            a.m, a.n, a.out, a.bias_out = m0 + j * width, width, outs[0].data_ptr(), bs[0].data_ptr()
+        assert lib.dd_conv_wgrad(ctypes.byref(a), None) == 0, lib.dd_last_error()
+        torch.cuda.synchronize()
+        return outs, bs
+    souts, sbs = call(True)
+    for j in range(nb):
+        pout, pb = call(False, j)
+        check("stacked dW block %d vs its own launch" % j, souts[j].cpu(), pout[0].cpu(), ACC32[dtype])
+        check("stacked db block %d vs its own launch" % j, sbs[j].cpu(), pb[0].cpu(), ACC32[dtype])
+    # block 0 against float64: dW[t][ci][co] = sum_p relu(x)[p + off(t)][ci] dy[p][co]
+    xs = torch.relu(buf[..., :m0].cpu().double()).permute(0, 3, 1, 2)
+    dy = grad[..., m0:m0 + width].cpu().double().permute(0, 3, 1, 2)
+    xp = torch.nn.functional.pad(xs, (1, 1, 1, 1))
+    want = torch.stack([torch.einsum("bchw,bdhw->cd", xp[:, :, a_:a_ + H, b_:b_ + W], dy) for a_ in range(3) for b_ in range(3)])
+    check("stacked dW block 0 vs float64", souts[0].cpu().double(), want, ACC32[dtype])
+    # a stacked call whose shapes do not add up is refused
+    a = L.WgradArgs()
+    a.p, a.ldp, a.m, a.q, a.ldq, a.n = buf.data_ptr(), ld, m + 8, grad.data_ptr() + m0 * esz, ld, n
+    a.B, a.H, a.W, a.taps, a.dtype, a.stack_blocks, a.stack_width, a.stack_m0 = B, H, W, 9, code, nb, width, m0
+    for i in range(nb):
+        a.stack_out[i] = souts[i].data_ptr()
+    assert lib.dd_conv_wgrad(ctypes.byref(a), None) != 0
