@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # compose / register-weight / transposed-conv kernels are HBM- or latency-bound: a spill there is silent HBM traffic (round 2 shipped a
 # compose backward that wrote 15x its algorithmic bytes to scratch).  A build in which one of them reports a non-zero ScratchSize is refused.
 NO_SCRATCH = {
-    "dd_conv_bwd.hip": ("conv_bwd_kernel",),
+    "dd_conv_bwd.hip": ("conv_bwd_kernel", "conv_bwd_multi_kernel"),
     "dd_pointwise.hip": ("kpcn_fwd_kernel", "kpcn_bwd_kernel", "assemble_input_kernel"),
     "dd_convt.hip": ("convt_bwd_kernel", "convt_fwd_kernel"),
     "dd_conv_rw.hip": ("conv_rw_kernel", "conv_rw8_kernel"),

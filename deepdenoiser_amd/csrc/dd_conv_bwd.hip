@@ -91,12 +91,11 @@ template <> __device__ __forceinline__ void bw_mma_inplace<f16_t>(f32x4_t& acc, 
 // destination registers shared with the row pointer, and hipcc guarded that with s_waitcnt vmcnt(0) once per output row -- a wait for every DMA
 // piece in flight, i.e. an HBM round trip 16 times per tile.
 template <typename T, bool MASK, bool ACCUM>
-__global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
+__device__ __forceinline__ void conv_bwd_body(const BwdP& a, char* smem, int block) {
   static_assert(sizeof(T) == 2, "fused conv backward: bf16 / fp16 storage");
   constexpr int PW = BW_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pair = blockIdx.x / a.ksplit, ks = blockIdx.x - pair * a.ksplit;
+  const int pair = block / a.ksplit, ks = block - pair * a.ksplit;
   const int cb = pair % a.nblk, ob = pair / a.nblk + (a.co_base >> 6);      // input- / output-channel block of this workgroup column
   const int wr = wave & 3;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -402,6 +401,29 @@ __global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
   dd_det_end();
 }
 
+template <typename T, bool MASK, bool ACCUM>
+__global__ __launch_bounds__(512) void conv_bwd_kernel(const BwdP a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  conv_bwd_body<T, MASK, ACCUM>(a, smem, blockIdx.x);
+}
+
+// Several weight-gradient-only problems on the same pixel grid as ONE launch (blockIdx.y picks the problem): the four 128-channel layers of the
+// U-Net's 32 x 32 level each ran 256 workgroups over 4 tiles apiece and then flushed 256 x 36 864 fp32 atomics -- a third of a 57-us launch
+// (7.2).  Side by side each problem gets a quarter of the workgroups with four times the tiles: the same MFMA work per workgroup, a quarter of
+// the atomics per problem, three launch boundaries fewer.
+constexpr int BW_MAX_MULTI = 4;
+struct BwdMulti { BwdP p[BW_MAX_MULTI]; int blocks[BW_MAX_MULTI]; };
+template <typename T>
+__global__ __launch_bounds__(512) void conv_bwd_multi_kernel(const BwdMulti m) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  if ((int)blockIdx.x >= m.blocks[blockIdx.y]) {      // (whole workgroups: no barrier is skipped by part of one)
+    dd_det_wait();                                    // (DD_DETERMINISTIC=1: an idle workgroup still takes and passes on its ticket in order)
+    dd_det_end();
+    return;
+  }
+  conv_bwd_body<T, false, false>(m.p[blockIdx.y], smem, blockIdx.x);
+}
+
 static int bwd_cus() {
   return dd_device_cus();
 }
@@ -424,7 +446,43 @@ int launch_bwd(const BwdP& p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
+static int bwd_fill(BwdP& p, const dd_conv_bwd_args* a);
+
+// weight / bias gradients only (dx = NULL) of up to BW_MAX_MULTI layers on the same [B, H, W] grid, one launch
+extern "C" int dd_conv3x3_bwd_multi(const dd_conv_bwd_args* a, int n, dd_stream stream) {
+  DD_REQUIRE(a && n >= 1 && n <= BW_MAX_MULTI, "dd_conv3x3_bwd_multi: 1 to %d problems", BW_MAX_MULTI);
+  BwdMulti m;
+  memset(&m, 0, sizeof(m));
+  long gx = 1;
+  for (int i = 0; i < n; ++i) {
+    DD_REQUIRE(a[i].dx == nullptr && a[i].B == a[0].B && a[i].H == a[0].H && a[i].W == a[0].W && a[i].dtype == a[0].dtype && !a[i].use_mask && !a[i].accumulate,
+               "dd_conv3x3_bwd_multi: problem %d: weight-gradient-only problems (dx = NULL) on one [B, H, W] grid and storage type", i);
+    if (int rc = bwd_fill(m.p[i], &a[i])) return rc;
+    BwdP& p = m.p[i];
+    const long total_tiles = (long)p.B * p.tiles_x * p.tiles_y;
+    p.nblk_co = dd_ceil_div(p.cout, 64);
+    long ksplit = bwd_cus() / ((long)n * p.nblk * p.nblk_co);
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > total_tiles) ksplit = total_tiles;
+    p.ksplit = (int)ksplit; p.co_base = 0; p.use_mask = 0; p.accumulate = 0;
+    m.blocks[i] = p.nblk * p.nblk_co * p.ksplit;
+    if (m.blocks[i] > gx) gx = m.blocks[i];
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t lds = 2 * (size_t)BW_BUF;
+  dd_det_sync();
+  if (a[0].dtype == DD_BF16) {
+    dd_allow_max_lds(reinterpret_cast<const void*>(conv_bwd_multi_kernel<bf16_t>));
+    hipLaunchKernelGGL(conv_bwd_multi_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)n), dim3(512), lds, s, m);
+  } else {
+    dd_allow_max_lds(reinterpret_cast<const void*>(conv_bwd_multi_kernel<f16_t>));
+    hipLaunchKernelGGL(conv_bwd_multi_kernel<f16_t>, dim3((unsigned)gx, (unsigned)n), dim3(512), lds, s, m);
+  }
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
+
+static int bwd_fill(BwdP& p, const dd_conv_bwd_args* a) {
   DD_REQUIRE(a && a->dy && a->x && a->dw && (a->wd || !a->dx), "dd_conv3x3_bwd: null pointer");      // dx (and then wd) may be NULL: weight / bias gradients only
   DD_REQUIRE(a->dtype == DD_BF16 || a->dtype == DD_F16, "dd_conv3x3_bwd: dtype %d (bf16 / f16 storage only; f32 takes dd_conv_igemm + dd_conv_wgrad)", a->dtype);
   DD_REQUIRE(a->cout > 0 && a->cin > 0, "dd_conv3x3_bwd: cout=%d cin=%d", a->cout, a->cin);
@@ -435,7 +493,6 @@ extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
              "dd_conv3x3_bwd: dy / x / wd must be 16-byte aligned, dx 8-byte aligned");
   DD_REQUIRE(!a->dx || (a->n_pad >= a->cin && a->k_pad >= a->cout && a->k_pad % 8 == 0), "dd_conv3x3_bwd: packed weights [9][n_pad=%d][k_pad=%d] do not cover %d x %d", a->n_pad, a->k_pad, a->cin, a->cout);
   DD_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && (long)a->B * a->H * a->W < (1L << 31) / 256, "dd_conv3x3_bwd: empty or oversized grid");
-  BwdP p;
   p.dy = a->dy; p.x = a->x; p.wd = a->wd; p.dx = a->dx; p.dw = a->dw; p.db = a->db;
   p.lddy = a->ld_dy; p.ldx = a->ld_x; p.lddx = a->ld_dx;
   p.cout = a->cout; p.cin = a->cin; p.coutv = coutv; p.cinv = cinv;
@@ -443,6 +500,13 @@ extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   p.B = a->B; p.H = a->H; p.W = a->W;
   p.tiles_x = dd_ceil_div(a->W, DD_TILE); p.tiles_y = dd_ceil_div(a->H, DD_TILE);
   p.nblk = dd_ceil_div(a->cin, 64);
+  p.nblk_co = 1; p.ksplit = 1; p.co_base = 0; p.use_mask = a->use_mask; p.accumulate = a->accumulate;
+  return DD_OK;
+}
+
+extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
+  BwdP p;
+  if (int rc = bwd_fill(p, a)) return rc;
   const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // Without a data gradient the output-channel blocks are workgroup columns of ONE launch.  With one, a launch covers 64 output channels (its

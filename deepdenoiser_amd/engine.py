@@ -288,6 +288,54 @@ class Graph:
         for builder in reversed(self._tape):
             builder()
         self._tape = []
+        self._merge_weights_only()
+
+    def _merge_weights_only(self, max_pixels=1 << 18, group=4):
+        """Weight-gradient-only launches of the fused backward kernel on one SMALL pixel grid (the 128-channel layers of the U-Net's 32 x 32 level:
+        B x 1 024 pixels) run side by side as one launch, at the position of the last of them (dd_conv3x3_bwd_multi): their operands -- a layer's
+        input and its output gradient -- are final from the original position on and nothing in between reads the weight gradients.  On a large
+        grid the flush this saves is a few per cent of the launch and the launches stay apart (DD_WGRAD_MULTI=0: always)."""
+        if os.environ.get("DD_WGRAD_MULTI", "1") == "0":
+            return
+        max_pixels = int(os.environ.get("DD_WGRAD_MULTI_PIXELS", max_pixels))
+        ops, lib = self.bwd_ops, self.lib
+        by_grid = {}
+        for i, op in enumerate(ops):
+            w = getattr(op, "weights_only", None)
+            if w is not None and w[1].B * w[1].H * w[1].W <= max_pixels:
+                by_grid.setdefault((w[1].B, w[1].H, w[1].W), []).append(i)
+        drop, put = set(), {}
+        for idxs in by_grid.values():
+            for g0 in range(0, len(idxs), group):
+                chunk = idxs[g0:g0 + group]
+                if len(chunk) < 2:
+                    continue
+                members = [ops[i].weights_only for i in chunk]
+                records = []
+                for gy, x, layer in members:
+                    rec = {"flops": 2.0 * x.B * x.H * x.W * 9 * layer.cin * layer.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "m": layer.cin, "n": layer.cout}
+                    self.wgrad_records.append(rec)
+                    records.append(rec)
+                info = dict(records[0], flops=sum(r["flops"] for r in records), merged=len(members))
+
+                def run(stream, members=members, cell=[]):
+                    if not cell:      # parameter pointers exist only after ParamStore.finalize()
+                        arr = (L.ConvBwdArgs * len(members))()
+                        for a, (gy, x, layer) in zip(arr, members):
+                            a.dy, a.ld_dy, a.cout = gy.ptr, gy.ld, layer.cout
+                            a.x, a.ld_x, a.cin = x.ptr, x.ld, layer.cin
+                            a.wd, a.n_pad, a.k_pad, a.dx, a.ld_dx = None, 0, 0, None, 0
+                            a.dw, a.db = self.params.grad_ptr(layer.kernel), self.params.grad_ptr(layer.bias)
+                            a.B, a.H, a.W, a.use_mask, a.accumulate, a.dtype = x.B, x.H, x.W, 0, 0, self.code
+                        cell.append(arr)
+                    L.check(lib.dd_conv3x3_bwd_multi(cell[0], len(members), stream))
+                run.tag, run.info = "conv_wgrad", info
+                run.grad_params = tuple(p for _, _, layer in members for p in (layer.kernel, layer.bias))
+                run.keep = [(gy.buf, x.buf) for gy, x, _ in members]
+                put[chunk[-1]] = run
+                drop.update(chunk[:-1])
+        if put:
+            self.bwd_ops = [put.get(i, op) for i, op in enumerate(ops) if i not in drop]
 
     # ------------------------------------------------------------------ conv launches
     def _conv_call(self, x, wp, taps, n_pad, k_pad, bias, nbias, res, mask, y, B, H, W, flags, nk=None):
@@ -509,6 +557,7 @@ class Graph:
                 # 128->128 at 32x32 71 -> 60 us against csrc/dd_conv_wgrad.hip
                 self.bwd(self._defer(lambda: self._conv_bwd_call(gy, x, layer, None, 0, 0, None, False, False, as_wgrad=True), "conv_wgrad"),
                          grad_params=[layer.kernel, layer.bias])
+                self.bwd_ops[-1].weights_only = (gy, x, layer)      # (build_backward may run several of these as one launch: _merge_weights_only)
             else:
                 self.bwd(self._defer(lambda: self._wgrad_call(x, layer.cin, gy, layer.cout, ps.grad_ptr(layer.kernel), x.B, x.H, x.W, taps, wflags,
                                                               ps.grad_ptr(layer.bias), 1), "conv_wgrad"), grad_params=[layer.kernel, layer.bias])

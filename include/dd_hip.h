@@ -138,6 +138,10 @@ typedef struct {
   int use_mask; int accumulate; int dtype;
 } dd_conv_bwd_args;
 int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream);
+/* the weight / bias gradients (dx = NULL) of n <= 4 layers on the SAME [B, H, W] grid as one launch (round 5: the 128-channel layers of the U-Net's
+ * coarsest level -- each problem gets a share of the workgroups with more tiles apiece, i.e. fewer fp32 atomics per problem and n - 1 launch
+ * boundaries fewer).  a: HOST array of n descriptors. */
+int dd_conv3x3_bwd_multi(const dd_conv_bwd_args* a, int n, dd_stream stream);
 
 /* ---- 2x2 / stride-2 transposed convolution (tf.layers.conv2d_transpose(filters, 2, strides=2), UNet.py:54-59) as streaming kernels: the
  * forward (+ bias, ReLU), and the data + weight + bias gradients of TensorFlow's autodiff (Training.py:701-702) in ONE launch.  bf16 / f16

@@ -936,3 +936,42 @@ def test_stacked_weight_gradients_of_a_dense_block_match_one_launch_per_conv(lib
     for i in range(nb):
         a.stack_out[i] = souts[i].data_ptr()
     assert lib.dd_conv_wgrad(ctypes.byref(a), None) != 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_weight_gradient_only_launches_side_by_side_match_their_own_launches(lib, dtype):
+    """dd_conv3x3_bwd_multi (round 5): the Conv2DBackpropFilter + BiasAddGrad ops (Training.py:701-702 over UNet.py:38-48) of several layers on one
+    pixel grid as one launch, against dd_conv3x3_bwd with dx = NULL per layer (fp32 atomics either way: ACC32) -- different channel counts per
+    problem (96 -> 128, 128 -> 128, 72 -> 40), ragged 20 x 12 images."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from deepdenoiser_amd import _lib as L
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    code = L.DD_BF16 if dtype == "bf16" else L.DD_F16
+    B, H, W = 3, 20, 12
+    shapes = [(96, 128), (128, 128), (72, 40), (128, 128)]
+    g = _gen(33)
+    xs = [representable(torch.relu(torch.randn(B, H, W, ci, generator=g, dtype=torch.float64)), dtype).to(tdt).cuda() for ci, _ in shapes]
+    dys = [representable(torch.randn(B, H, W, co, generator=g, dtype=torch.float64), dtype).to(tdt).cuda() for _, co in shapes]
+
+    def args(arr, outs):
+        for a, x, dy, (ci, co), (dw, db) in zip(arr, xs, dys, shapes, outs):
+            a.dy, a.ld_dy, a.cout, a.x, a.ld_x, a.cin = dy.data_ptr(), co, co, x.data_ptr(), ci, ci
+            a.dw, a.db, a.B, a.H, a.W, a.dtype = dw.data_ptr(), db.data_ptr(), B, H, W, code
+    mk = lambda: [(torch.zeros(9, ci, co).cuda(), torch.zeros(co).cuda()) for ci, co in shapes]
+    multi, single = mk(), mk()
+    arr = (L.ConvBwdArgs * len(shapes))()
+    args(arr, multi)
+    assert lib.dd_conv3x3_bwd_multi(arr, len(shapes), None) == 0, lib.dd_last_error()
+    arr1 = (L.ConvBwdArgs * len(shapes))()
+    args(arr1, single)
+    for i in range(len(shapes)):
+        assert lib.dd_conv3x3_bwd(ctypes.byref(arr1[i]), None) == 0, lib.dd_last_error()
+    torch.cuda.synchronize()
+    for i, ((dw, db), (dw1, db1)) in enumerate(zip(multi, single)):
+        check("side-by-side dW %d" % i, dw.cpu(), dw1.cpu(), ACC32[dtype])
+        check("side-by-side db %d" % i, db.cpu(), db1.cpu(), ACC32[dtype])
+    assert float(multi[0][0].abs().max()) > 0
+    arr[1].H = H + 1      # problems on different grids are refused
+    assert lib.dd_conv3x3_bwd_multi(arr, len(shapes), None) != 0
+    assert lib.dd_conv3x3_bwd_multi(arr, 5, None) != 0
