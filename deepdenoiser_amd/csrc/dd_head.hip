@@ -642,27 +642,31 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
 #ifndef HB_EXP_NO_FLUSH
   dd_det_wait();      // (DD_DETERMINISTIC=1: workgroups flush in index order, dd_common.h)
   if (threadIdx.x < 256) {
-    int t = 0;
-    for (int i = 0; i < NPT; ++i)
-      for (int j = 0; j < NPT; ++j, ++t) {
+    // Every workgroup starts at its own tile (round 5): 256 workgroups walking the same ~3 900 addresses in the same order at the same time serialise
+    // in the atomic units -- 42 % of the 32 x 32 scale's launch was this flush (tools/head_phases.py; tools/ubench/atomic_scope.hip mode 3).
+    for (int tt = 0; tt < NTILES; ++tt) {
+      int t = tt + (int)(blockIdx.x % NTILES);
+      if (t >= NTILES) t -= NTILES;
+      const float v = red[t * 256 + fl * 4 + fe];
+      if (t < NPT * NPT) {                                            // dWb[pos m][pos n]; row ONES: d bb
+        const int i = t / NPT, j = t - i * NPT;
         const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = i * 16 + fq * 4 + fe, m = pos_ch(pos);
         const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
-        const float v = red[t * 256 + fl * 4 + fe];
         if (!n_ok) continue;
         if (pos == ONES) atomicAdd(a.dbb + n, v);
         else if (((pos & 7) >> 2) < NT && m < K) atomicAdd(a.dwb + m * K + n, v);
-      }
-    for (int j = 0; j < NPT; ++j, ++t) {
-      const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = (ONES >> 4) * 16 + fq * 4 + fe;
-      const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
-      if (n_ok && pos == ONES) atomicAdd(a.dba + n, red[t * 256 + fl * 4 + fe]);
-    }
-    for (int ct = 0; ct < CT; ++ct)
-      for (int j = 0; j < NPT; ++j, ++t) {
+      } else if (t < NPT * NPT + NPT) {                               // row ONES: d ba
+        const int j = t - NPT * NPT;
+        const int cpos = j * 16 + fli, n = pos_ch(cpos), pos = (ONES >> 4) * 16 + fq * 4 + fe;
+        const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
+        if (n_ok && pos == ONES) atomicAdd(a.dba + n, v);
+      } else {                                                        // dWa[c][pos m]
+        const int u = t - NPT * NPT - NPT, ct = u / NPT, j = u - ct * NPT;
         const int cpos = j * 16 + fli, n = pos_ch(cpos), c = ct * 16 + fq * 4 + fe;
         const bool n_ok = ((cpos & 7) >> 2) < NT && n < K;
-        if (n_ok && c < a.C) atomicAdd(a.dwa + (long)c * K + n, red[t * 256 + fl * 4 + fe]);
+        if (n_ok && c < a.C) atomicAdd(a.dwa + (long)c * K + n, v);
       }
+    }
   }
 #endif
   HPH(7);
