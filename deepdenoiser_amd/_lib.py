@@ -22,7 +22,7 @@ SYMBOLS = (
     "dd_compose_unpack_bwd", "dd_invert_std_fwd", "dd_invert_std_bwd", "dd_loss_head", "dd_adam_step",
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
-    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_assemble_input", "dd_assemble_input_frames", "dd_conv3x3_bwd", "dd_conv3x3_bwd_multi", "dd_convt2x2_fwd", "dd_convt2x2_bwd", "dd_conv3x3_ks",
+    "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_kpcn_head_bwd_multi", "dd_assemble_input", "dd_assemble_input_frames", "dd_conv3x3_bwd", "dd_conv3x3_bwd_multi", "dd_convt2x2_fwd", "dd_convt2x2_bwd", "dd_conv3x3_ks",
     "dd_conv_pw_count", "dd_wgrad_pw_count", "dd_space_to_depth2", "dd_convt3_wgrad", "dd_conv3x3_pair", "dd_compose_stream_plan", "dd_compose_bwd_scratch_bytes",
 )
 
@@ -281,6 +281,7 @@ def load():
     lib.dd_assemble_input_frames.argtypes = [vp, i, i, vp, i, i, i, i, i, i, vp, i, i, vp]
     lib.dd_kpcn_head_fwd.argtypes = [C.POINTER(HeadArgs), vp]
     lib.dd_kpcn_head_bwd.argtypes = [C.POINTER(HeadArgs), vp]
+    lib.dd_kpcn_head_bwd_multi.argtypes = [C.POINTER(HeadArgs), i, vp]
     _lib = lib
     return lib
 

@@ -29,7 +29,7 @@ NO_SCRATCH = {
     "dd_convt.hip": ("convt_bwd_kernel", "convt_fwd_kernel"),
     "dd_conv_rw.hip": ("conv_rw_kernel", "conv_rw8_kernel"),
     "dd_compose.hip": ("compose_fwd_kernel", "compose_bwd_kernel"),
-    "dd_head.hip": ("head_fwd_kernel", "head_bwd_kernel"),
+    "dd_head.hip": ("head_fwd_kernel", "head_bwd_kernel", "head_bwd_multi_kernel"),
     "dd_conv_ks.hip": ("conv_ks_kernel",),
     "dd_conv_pw.hip": ("conv_pw_kernel", "wgrad_pw_kernel"),
     "dd_conv_pair.hip": ("conv_pair_kernel",),

@@ -341,19 +341,20 @@ template <int NCH> struct HeadStrip {
 constexpr int BWD_WAVES = 8;      // one persistent workgroup per CU, 2 waves per SIMD (a wave's 32-pixel step is a chain of memory round trips)
 // ACCUM (d x is added to a gradient already stored) is a template flag: as a runtime branch the never-taken side still cost the 2 * NCH * 2
 // registers of the old gradient, and the 128-channel instantiation spilled 55 registers (round 2).
+// wg / nwgs: this workgroup's index among the workgroups of ITS problem (a launch may run several scales side by side: head_bwd_multi_kernel)
 template <typename T, int KS, int NCH, bool ACCUM>
-__global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a) {
-  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, P = HeadDim<KS>::P, ONES = HeadDim<KS>::ONES_POS;
+__device__ __forceinline__ void head_bwd_body(const HeadP a, char* smem, int wg_, int nwgs_) {      // (by value: through a reference the 128-channel instantiation spilled 8 registers)
+  const int wg = __builtin_amdgcn_readfirstlane(wg_), nwgs = __builtin_amdgcn_readfirstlane(nwgs_);      // (workgroup-uniform: scalar registers)
+  constexpr int K = HeadDim<KS>::K, NT = HeadDim<KS>::NT, ONES = HeadDim<KS>::ONES_POS;
   constexpr int CT = NCH * 2;                          // 16-channel tiles of x
   constexpr int XROW = HeadStrip<NCH>::XROW, HROW = HeadStrip<NCH>::HROW, STRIP = HeadStrip<NCH>::BYTES;
   constexpr int NA1 = HeadDim<KS>::NT * NCH;           // fragment-ready operand image behind the strips (forward_gemms_lds): a1, a4, a3, a2, b1, b2
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* s_hid = smem + wv * STRIP;                     // [32 px][32 slots] hid (slot order, position ONES := 1)
   char* s_dl = s_hid + 32 * HROW;                      // [32 px][32 slots] d logits
   char* s_dh = s_dl + 32 * HROW;                       // [32 px][32 slots] d hid (pre-activation)
   char* s_x = s_dh + 32 * HROW;                        // [32 px][NCH * 32 channels] x      (rows HROW / XROW bytes apart: HeadStrip)
-  const long wave = (long)blockIdx.x * BWD_WAVES + wv, nwaves = (long)gridDim.x * BWD_WAVES;
+  const long wave = (long)wg * BWD_WAVES + wv, nwaves = (long)nwgs * BWD_WAVES;
 
   HPH_DECL();
   const HeadW hw = stage_head_weights<KS>(reinterpret_cast<float*>(smem), a, BWD_WAVES * 64);      // (the strips are not in use yet)
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
     // Every workgroup starts at its own tile (round 5): 256 workgroups walking the same ~3 900 addresses in the same order at the same time serialise
     // in the atomic units -- 42 % of the 32 x 32 scale's launch was this flush (tools/head_phases.py; tools/ubench/atomic_scope.hip mode 3).
     for (int tt = 0; tt < NTILES; ++tt) {
-      int t = tt + (int)(blockIdx.x % NTILES);
+      int t = tt + wg % NTILES;
       if (t >= NTILES) t -= NTILES;
       const float v = red[t * 256 + fl * 4 + fe];
       if (t < NPT * NPT) {                                            // dWb[pos m][pos n]; row ONES: d bb
@@ -671,6 +672,33 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a)
 #endif
   HPH(7);
   dd_det_end();
+}
+
+template <typename T, int KS, int NCH, bool ACCUM>
+__global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_kernel(const HeadP a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  head_bwd_body<T, KS, NCH, ACCUM>(a, smem, blockIdx.x, gridDim.x);
+}
+
+// The backward of several scales as ONE launch (round 5): the scales' launches are independent, and the small ones are mostly fixed cost -- at the
+// 32 x 32 scale the pixel loop is 35 % of the launch (tools/head_phases.py: weight staging, fragment images, the wait for the slowest wave, the
+// flush), at 64 x 64 65 %.  Side by side every workgroup pays its fixed cost while the others multiply; workgroups [first[y], first[y + 1]) run
+// problem y, split by the host in proportion to the problems' pixel-loop work.
+constexpr int HEAD_MAX_MULTI = 3;
+struct HeadMultiP { HeadP p[HEAD_MAX_MULTI]; int nch[HEAD_MAX_MULTI]; int first[HEAD_MAX_MULTI + 1]; int n; };
+template <typename T, int KS>
+__global__ __launch_bounds__(BWD_WAVES * 64) void head_bwd_multi_kernel(const HeadMultiP m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int y = 0;
+  while (y + 1 < m.n && (int)blockIdx.x >= m.first[y + 1]) ++y;
+  const HeadP& a = m.p[y];
+  const int wg = blockIdx.x - m.first[y], nwgs = m.first[y + 1] - m.first[y];
+#define HB_CASE(N_)                                                                   \
+  case N_: if (a.accumulate) head_bwd_body<T, KS, N_, true>(a, smem, wg, nwgs);      \
+           else head_bwd_body<T, KS, N_, false>(a, smem, wg, nwgs);                  \
+           break;
+  switch (m.nch[y]) { HB_CASE(1) HB_CASE(2) HB_CASE(3) default: if (a.accumulate) head_bwd_body<T, KS, 4, true>(a, smem, wg, nwgs); else head_bwd_body<T, KS, 4, false>(a, smem, wg, nwgs); }
+#undef HB_CASE
 }
 
 static int head_cus() { return dd_device_cus(); }
@@ -738,7 +766,72 @@ int head_common(const dd_head_args* a, bool backward, dd_stream stream) {
   return a->dtype == DD_BF16 ? dispatch_ks<bf16_t>(p, a->ksize, backward, s) : dispatch_ks<f16_t>(p, a->ksize, backward, s);
 }
 
+template <typename T, int KS>
+static void launch_head_bwd_multi(const HeadMultiP& m, size_t lds, int wgs, hipStream_t s) {
+  dd_det_sync();
+  dd_allow_max_lds(reinterpret_cast<const void*>(head_bwd_multi_kernel<T, KS>));
+  hipLaunchKernelGGL((head_bwd_multi_kernel<T, KS>), dim3((unsigned)wgs), dim3(BWD_WAVES * 64), lds, s, m);
+}
+static size_t head_bwd_lds(int ks, int nch) {
+  const int nt = ks == 5 ? HeadDim<5>::NT : HeadDim<3>::NT;
+  const size_t strip = nch == 1 ? HeadStrip<1>::BYTES : nch == 2 ? HeadStrip<2>::BYTES : nch == 3 ? HeadStrip<3>::BYTES : HeadStrip<4>::BYTES;
+  return BWD_WAVES * strip + (size_t)(nt * nch + nch * 2 + 4 * nt) * 1024;
+}
+
 }  // namespace
+
+// The backward of up to three scales' heads as one launch (same storage type and kernel size): see head_bwd_multi_kernel.
+extern "C" int dd_kpcn_head_bwd_multi(const dd_head_args* a, int n, dd_stream stream) {
+  DD_REQUIRE(a && n >= 1 && n <= HEAD_MAX_MULTI, "dd_kpcn_head_bwd_multi: 1 to %d problems", HEAD_MAX_MULTI);
+  if (n == 1) return dd_kpcn_head_bwd(a, stream);
+  HeadMultiP m;
+  memset(&m, 0, sizeof(m));
+  m.n = n;
+  double work[HEAD_MAX_MULTI], total = 0.0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const dd_head_args* b = a + i;
+    DD_REQUIRE(b->x && b->src && b->wa && b->ba && b->wb && b->bb, "dd_kpcn_head_bwd_multi: null pointer (problem %d)", i);
+    DD_REQUIRE((b->dtype == DD_BF16 || b->dtype == DD_F16) && b->dtype == a->dtype && b->ksize == a->ksize && (b->ksize == 3 || b->ksize == 5),
+               "dd_kpcn_head_bwd_multi: one storage type (bf16 / f16) and one kernel size (3, 5) per launch");
+    DD_REQUIRE(b->C > 0 && b->C <= 128 && b->C % 8 == 0 && b->ldx >= b->C && b->ldx % 8 == 0 && ((uintptr_t)b->x % 16) == 0, "dd_kpcn_head_bwd_multi: C=%d ldx=%d (problem %d)", b->C, b->ldx, i);
+    DD_REQUIRE(b->N > 0 && b->H > 0 && b->W > 0 && b->ldsrc >= 3 && b->H >= (b->ksize - 1) / 2 && b->W >= (b->ksize - 1) / 2, "dd_kpcn_head_bwd_multi: bad shape (problem %d)", i);
+    DD_REQUIRE(b->dout && b->ld_dout >= 3 && b->dx && b->ld_dx >= b->C && b->ld_dx % 4 == 0 && b->dwa && b->dba && b->dwb && b->dbb, "dd_kpcn_head_bwd_multi: null gradient pointer (problem %d)", i);
+    HeadP& p = m.p[i];
+    p.x = b->x; p.src = b->src; p.wa = b->wa; p.ba = b->ba; p.wb = b->wb; p.bb = b->bb; p.out = b->out;
+    p.dout = b->dout; p.dx = b->dx; p.dwa = b->dwa; p.dba = b->dba; p.dwb = b->dwb; p.dbb = b->dbb;
+    p.ldx = b->ldx; p.C = b->C; p.ldsrc = b->ldsrc; p.ldo = b->ld_out; p.lddo = b->ld_dout; p.lddx = b->ld_dx; p.accumulate = b->accumulate_dx;
+    p.N = b->N; p.H = b->H; p.W = b->W; p.npix = (long)b->N * b->H * b->W;
+    m.nch[i] = (b->C + 31) / 32;
+    // measured cycles per 32-pixel step of a wave (tools/head_phases.py, 5 x 5): 32 / 64 / 96 / 128 channels
+    static double step_cost[5] = {0.0, 12.0, 17.0, 16.0, 23.0};
+    static const bool tuned = [] { const char* e = getenv("DD_HEAD_MULTI_W"); if (e) sscanf(e, "%lf,%lf,%lf,%lf", &step_cost[1], &step_cost[2], &step_cost[3], &step_cost[4]); return true; }();
+    (void)tuned;
+    work[i] = (double)((p.npix + 31) / 32) * step_cost[m.nch[i]] + 2.0 * BWD_WAVES * step_cost[m.nch[i]];      // (+ a fixed share: nobody gets zero workgroups)
+    total += work[i];
+    const size_t l = head_bwd_lds(b->ksize, m.nch[i]);
+    if (l > lds) lds = l;
+  }
+  const int cus = head_cus();
+  int left = cus;
+  m.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    int w = i == n - 1 ? left : (int)(cus * work[i] / total + 0.5);
+    const long steps = (m.p[i].npix + 31) / 32;
+    if (w < 1) w = 1;
+    if ((long)w * BWD_WAVES > steps) w = (int)((steps + BWD_WAVES - 1) / BWD_WAVES);
+    if (w > left - (n - 1 - i)) w = left - (n - 1 - i);
+    if (w < 1) w = 1;
+    m.first[i + 1] = m.first[i] + w;
+    left -= w;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int wgs = m.first[n];
+  if (a->dtype == DD_BF16) { if (a->ksize == 5) launch_head_bwd_multi<bf16_t, 5>(m, lds, wgs, s); else launch_head_bwd_multi<bf16_t, 3>(m, lds, wgs, s); }
+  else { if (a->ksize == 5) launch_head_bwd_multi<f16_t, 5>(m, lds, wgs, s); else launch_head_bwd_multi<f16_t, 3>(m, lds, wgs, s); }
+  DD_LAUNCH_CHECK();
+  return DD_OK;
+}
 
 extern "C" int dd_kpcn_head_fwd(const dd_head_args* a, dd_stream stream) { return head_common(a, false, stream); }
 extern "C" int dd_kpcn_head_bwd(const dd_head_args* a, dd_stream stream) { return head_common(a, true, stream); }

@@ -276,6 +276,9 @@ typedef struct {
 } dd_head_args;
 int dd_kpcn_head_fwd(const dd_head_args* a, dd_stream stream);
 int dd_kpcn_head_bwd(const dd_head_args* a, dd_stream stream);
+/* the backward of n <= 3 scales' heads (HOST array; one storage type and kernel size) as ONE launch: the scales are independent and the coarse
+ * ones are mostly fixed cost (weight staging, the flush); side by side they share the device in proportion to their pixel counts (round 5) */
+int dd_kpcn_head_bwd_multi(const dd_head_args* a, int n, dd_stream stream);
 
 /* ---- multiscale compose (MultiScalePrediction.compose_scales, MultiScalePrediction.py:36-54) */
 /* net input = concat(nearest_x2(small), fine), zero padded to c_pad channels */

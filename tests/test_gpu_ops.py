@@ -975,3 +975,53 @@ def test_weight_gradient_only_launches_side_by_side_match_their_own_launches(lib
     arr[1].H = H + 1      # problems on different grids are refused
     assert lib.dd_conv3x3_bwd_multi(arr, len(shapes), None) != 0
     assert lib.dd_conv3x3_bwd_multi(arr, 5, None) != 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_head_backward_of_three_scales_side_by_side_matches_their_own_launches(lib, dtype):
+    """dd_kpcn_head_bwd_multi (round 5): the autodiff of AdjustNumberOfChannels + KernelPredictor (Architecture.py:237-289, KernelPrediction.py:11-63)
+    of three scales as ONE launch against dd_kpcn_head_bwd per scale: dx bit-identical (a workgroup's pixels change, nothing inside a pixel),
+    weight / bias gradients at fp32 summation order (ACC32) -- 64 / 96 / 128 channels, ragged images, one scale accumulating into dx."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from deepdenoiser_amd import _lib as L
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    code = L.DD_BF16 if dtype == "bf16" else L.DD_F16
+    g = _gen(41)
+    N, K = 3, 25
+    shapes = [(64, 40, 36), (96, 20, 18), (128, 10, 9)]
+    probs = []
+    for C, H, W in shapes:
+        d = {"x": representable(torch.relu(torch.randn(N, H, W, C, generator=g, dtype=torch.float64)), dtype).to(tdt).cuda(),
+             "src": torch.randn(N, H, W, 3, generator=g).cuda(), "dout": torch.randn(N, H, W, 3, generator=g).cuda(),
+             "wa": (torch.randn(C, K, generator=g) / C ** 0.5).cuda(), "ba": (0.1 * torch.randn(K, generator=g)).cuda(),
+             "wb": (torch.randn(K, K, generator=g) / 5).cuda(), "bb": (0.1 * torch.randn(K, generator=g)).cuda(),
+             "dx0": representable(torch.randn(N, H, W, C, generator=g, dtype=torch.float64), dtype).to(tdt).cuda()}
+        probs.append(d)
+
+    def fill(a, d, outs, accumulate):
+        C = d["x"].shape[3]
+        a.x, a.ldx, a.C, a.src, a.ldsrc = d["x"].data_ptr(), C, C, d["src"].data_ptr(), 3
+        a.wa, a.ba, a.wb, a.bb = d["wa"].data_ptr(), d["ba"].data_ptr(), d["wb"].data_ptr(), d["bb"].data_ptr()
+        a.dout, a.ld_dout, a.dx, a.ld_dx, a.accumulate_dx = d["dout"].data_ptr(), 3, outs["dx"].data_ptr(), C, accumulate
+        a.dwa, a.dba, a.dwb, a.dbb = outs["dwa"].data_ptr(), outs["dba"].data_ptr(), outs["dwb"].data_ptr(), outs["dbb"].data_ptr()
+        a.N, a.H, a.W, a.ksize, a.dtype = N, d["x"].shape[1], d["x"].shape[2], 5, code
+    mk = lambda d: {"dx": d["dx0"].clone(), "dwa": torch.zeros_like(d["wa"]), "dba": torch.zeros_like(d["ba"]), "dwb": torch.zeros_like(d["wb"]),
+                    "dbb": torch.zeros_like(d["bb"])}
+    multi, single = [mk(d) for d in probs], [mk(d) for d in probs]
+    arr = (L.HeadArgs * 3)()
+    for k in range(3):
+        fill(arr[k], probs[k], multi[k], 1 if k == 1 else 0)
+    assert lib.dd_kpcn_head_bwd_multi(arr, 3, None) == 0, lib.dd_last_error()
+    one = (L.HeadArgs * 3)()
+    for k in range(3):
+        fill(one[k], probs[k], single[k], 1 if k == 1 else 0)
+        assert lib.dd_kpcn_head_bwd(ctypes.byref(one[k]), None) == 0, lib.dd_last_error()
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert torch.equal(multi[k]["dx"], single[k]["dx"]), k
+        assert float(multi[k]["dx"].float().abs().max()) > 0
+        for name in ("dwa", "dba", "dwb", "dbb"):
+            check("side-by-side head %s scale %d" % (name, k), multi[k][name].cpu(), single[k][name].cpu(), ACC32[dtype])
+    arr[2].ksize = 3
+    assert lib.dd_kpcn_head_bwd_multi(arr, 3, None) != 0      # one kernel size per launch
