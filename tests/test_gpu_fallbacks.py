@@ -28,6 +28,10 @@ CASES = {   # name: (environment of the child, -k expression[, test file (defaul
     # the inverse standardization as launches of its own -- the path that still carries the variation terms
     "older_loss_kernel_unfused": ({"DD_LOSS_SIMPLE": "0", "DD_LOSS_GENERAL": "0", "DD_FUSE_LOSS_INVERT": "0"},
                                   "(test_training_step_parity_f32 and (example_json or cfg2)) or test_masked_mean", "test_gpu_model.py"),
+    # ... and the launches round 5 merged, apart again: one weight-gradient launch per conv of a dense block and per 128-channel layer, one head
+    # backward per scale, the per-channel-lane column sums, thin layers K-streamed
+    "round5_merges_off": ({"DD_WGRAD_STACK": "0", "DD_WGRAD_MULTI": "0", "DD_HEAD_BWD_MULTI": "0", "DD_COLSUM_VEC": "0", "DD_CONV_KS_THIN": "1"},
+                          "test_small_networks_half_precision or test_backward_of_the_fused or test_cfg2_full_size_half", "test_gpu_round3.py"),
     "tile_compose_kernels_bit_faithful": ({"DD_COMPOSE_STREAM": "0", "DD_COMPOSE_STREAM_BWD": "0"},
                                           "test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful", "test_gpu_round3.py"),
 }
