@@ -121,6 +121,12 @@ class ParamStore:
                 host[p.offset:p.offset + p.size] = (torch.rand(p.size, generator=gen) * 2 - 1) * limit
         self.values.copy_(host)
 
+    def state_key(self):
+        """Changes whenever the values may have: torch counts the in-place writes it performs on the arena and its views (load_list, checkpoint
+        restore, tests), launches that write through the raw pointer (dd_adam_step) count themselves in `raw_writes`.  Lets an inference loop
+        skip re-packing unchanged weights (prediction.Predictor)."""
+        return (self.values._version, getattr(self, "raw_writes", 0)) if self.values is not None else None
+
     def value(self, p):
         return self.values[p.offset:p.offset + p.size].view(p.shape)
 

@@ -209,6 +209,45 @@ def test_frame_input_read_in_place_is_bit_identical_to_extracted_tiles(dtype, mo
     assert pred._plans[(H, W)][1].frame_input is None
 
 
+def test_predictor_repacks_the_weights_when_they_changed_and_only_then(monkeypatch):
+    """A frame sequence runs on fixed weights: the Predictor skips dd_pack_weights_batched while ParamStore.state_key() stands still (round 5) and
+    must notice every way the values can change -- load_list (torch writes) and an optimizer step (a launch writing through the raw pointer)."""
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.prediction import Predictor
+    aj = configs.cfg2_unet_kpcn(filters=(16, 24, 32), convs=2)
+    H, W, T, O = 96, 128, 64, 10
+    key = Naming.feature_prediction_name("Emission")
+    g = torch.Generator().manual_seed(9)
+    arch = Architecture(aj, device="cuda", dtype="f16", seed=4)
+    frame = {Naming.source_feature_name(f.name, index=0): torch.randn(H, W, f.number_of_channels, generator=g).abs().cuda()
+             for f in arch.feature_predictions + arch.auxiliary_features}
+    pred = Predictor(arch, tile_size=T, tile_overlap_size=O, tiles_per_batch=8)
+    a = pred.predict_frame(frame)[key].clone()
+    prog = pred._plans[(H, W)][1]
+    packs = []
+    orig = prog.pack_weights
+    monkeypatch.setattr(prog, "pack_weights", lambda: (packs.append(1), orig())[1])
+    assert torch.equal(pred.predict_frame(frame)[key], a) and not packs          # same weights: no re-pack, same frame
+    new = [arch.params.value(p).clone() * 1.05 for p in arch.params.params]
+    arch.params.load_list(new)
+    b = pred.predict_frame(frame)[key].clone()
+    assert len(packs) == 1 and not torch.equal(a, b)
+    monkeypatch.setenv("DD_PACK_EVERY_FRAME", "1")
+    assert torch.equal(pred.predict_frame(frame)[key], b) and len(packs) == 2   # the reference behaviour gives the same frame
+    monkeypatch.delenv("DD_PACK_EVERY_FRAME")
+    # a training step on the same parameters (dd_adam_step writes through the raw pointer) is noticed too
+    tprog = arch.program(2, 32, 32, training_json=configs.bench_training())
+    feats, labels = {}, {}
+    for f in arch.feature_predictions + arch.auxiliary_features:
+        feats[Naming.source_feature_name(f.name, index=0)] = torch.rand(2, 32, 32, f.number_of_channels, device="cuda")
+    for f in arch.feature_predictions:
+        labels[Naming.target_feature_name(f.name)] = torch.rand(2, 32, 32, f.number_of_channels, device="cuda")
+    tprog.train_step(feats, labels)
+    c = pred.predict_frame(frame)[key]
+    assert len(packs) == 3 and not torch.equal(b, c)
+
+
 def test_predictor_one_hot_flags_match_the_oracle():
     """ONE_HOT_ENCODING at inference: the constant one-hot planes the reference's prediction input_fn adds (Prediction.py:97-98,
     FeatureFlags.add_to_source_dictionary) are supplied by the Predictor itself."""
