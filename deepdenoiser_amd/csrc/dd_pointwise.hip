@@ -290,6 +290,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restri
       packed[w] |= (uint32_t)k << (8 * e);
     }
   }
+  if (idx == nullptr) return;      // (inference: nobody reads the argmax plane)
   if (N == 8) *reinterpret_cast<uint2*>(idx + opix * C + c) = make_uint2(packed[0], packed[N / 4 - 1]);
   else *reinterpret_cast<uint32_t*>(idx + opix * C + c) = packed[0];
 }
@@ -310,7 +311,7 @@ extern "C" int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t*
                               int pool, int stride, int relu_mask, int dtype, dd_stream stream) {
   const int per16 = dtype == DD_F32 ? 4 : 8;
   DD_REQUIRE(dd_dtype_ok(dtype), "bad dtype %d", dtype);
-  DD_REQUIRE(x && y && idx && C % per16 == 0 && ldx % per16 == 0 && ldy % per16 == 0, "dd_maxpool_fwd: C, ld must be multiples of %d", per16);
+  DD_REQUIRE(x && y && C % per16 == 0 && ldx % per16 == 0 && ldy % per16 == 0, "dd_maxpool_fwd: C, ld must be multiples of %d", per16);      // (idx may be NULL: forward only)
   DD_REQUIRE(pool * pool < 255, "dd_maxpool_fwd: pool=%d too large", pool);
   int OH, OW, pby, pbx;
   same_pad(H, pool, stride, &OH, &pby); same_pad(W, pool, stride, &OW, &pbx);

@@ -901,11 +901,13 @@ class Graph:
         OH, OW = -(-x.H // stride), -(-x.W // stride)
         y = out if out is not None else self.tensor(x.B, OH, OW, x.C, requires_grad=x.requires_grad)
         assert (y.H, y.W, y.C) == (OH, OW, x.C)
-        idx = torch.zeros((x.B, OH, OW, x.Cp), dtype=torch.uint8, device=self.device)
+        # the argmax plane only feeds the backward: inference graphs do not store it
+        idx = torch.zeros((x.B, OH, OW, x.Cp), dtype=torch.uint8, device=self.device) if (bool(getattr(self, "training", True)) or os.environ.get("DD_MAXPOOL_KEEP_IDX", "0") == "1") else None
         lib, code = self.lib, self.code
 
         def run(stream):
-            L.check(lib.dd_maxpool_fwd(x.ptr, x.ld, y.ptr, y.ld, idx.data_ptr(), x.Cp, x.B, x.H, x.W, pool, stride, 1 if x.relu else 0, code, stream))
+            L.check(lib.dd_maxpool_fwd(x.ptr, x.ld, y.ptr, y.ld, idx.data_ptr() if idx is not None else None, x.Cp, x.B, x.H, x.W, pool, stride,
+                                       1 if x.relu else 0, code, stream))
         self.fwd(run, "maxpool")
 
         def backward():

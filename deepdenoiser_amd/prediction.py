@@ -79,7 +79,7 @@ class Predictor:
         H, W = frame[names[0]].shape[0], frame[names[0]].shape[1]
         plan, prog, chunks = self._frame_plan(H, W)
         T, NF = plan.tile, prog.NF
-        frames = torch.zeros((NF, H, W, 3), dtype=torch.float32, device=dev)
+        frames = torch.empty((NF, H, W, 3), dtype=torch.float32, device=dev)      # (the crops of the tile plan cover every pixel exactly once: tests/test_tiling_golden.py)
         # the MFMA operand images are re-packed only when the weights may have changed since this program last packed them (a frame sequence
         # runs on fixed weights: 30 us per 1080p frame); DD_PACK_EVERY_FRAME=1: always
         key = arch.params.state_key()

@@ -201,7 +201,7 @@ int dd_colsum_segments(const void* x, int ld, int c, long rows_per_segment, int 
 
 /* ---- max pooling, TF SAME (UNet.py:42-44 3x3/s2; Tiramisu.py:55-57 2x2/s2); idx = window argmax (uint8).
  * relu_mask != 0: x is a ReLU output whose backward mask (x > 0) is folded into idx (255 = the window maximum is not positive, no
- * gradient), so dd_maxpool_bwd can be called with mask == NULL. */
+ * gradient), so dd_maxpool_bwd can be called with mask == NULL.  idx == NULL: forward only (inference), no argmax plane is stored. */
 int dd_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int C, int B, int H, int W,
                    int pool, int stride, int relu_mask, int dtype, dd_stream stream);
 /* dx (+)= scatter(dy) masked by (mask>0) if mask != NULL */
