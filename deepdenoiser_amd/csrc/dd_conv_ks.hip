@@ -11,7 +11,8 @@
 //     multiplied), exactly as in conv_rw8_kernel;
 //   * the slice's weights (9 taps x 2 K-chunks = 18 MFMA A fragments = 72 registers per wave) are loaded straight from the packed image in L2
 //     into REGISTERS, one slice ahead (a second set of 72 registers; the unit loop is unrolled by two so the sets swap by name, not by moves).
-//     Every CU reads the same 72 KB per slice: an L2 stream, not an HBM one;
+//     Every CU reads the same 72 KB per slice: an L2 stream, not an HBM one (workgroups of <= 32 output channels: once per WORKGROUP, through LDS --
+//     KS_WLDS below);
 //   * the 8 rows x 16 channels of a wave's output stay in 32 accumulator registers across all slices and leave once, after the last one.
 // Per slice and SIMD: 2 waves x 144 MFMAs x 16 cycles = 4 608 cycles for 41 KiB of DMA + 72 KiB of weight loads = 24 B/clk/CU at full MFMA rate.
 // A workgroup covers a 16 x 16 pixel tile x (CT x 16) output channels: CT = 4 (64 channels: wave = channel tile x upper / lower 8 rows), 2 or 1
@@ -41,6 +42,17 @@ struct KsMulti { KsP p; KsSub sub[KS_MAX_SUB]; int in_relu, gather; };
 #endif
 typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KS_PW = DD_TILE + 2, KS_PH = DD_TILE + 2, KS_CH = (KS_PW * KS_PH + 7) / 8, KS_BUF = KS_CH * 1024;      // 41 KiB per buffer
+// Round 5: a workgroup of <= 32 output channels (CT = 1, 2) shares a K-slice's weights through LDS -- 9 taps x CT x 16 rows x 128 bytes arrive by
+// LDS-DMA once per workgroup, double buffered behind the two input buffers, and every wave reads its 18 fragments from there at the top of a unit.
+// With the register path all eight waves of a 16-channel workgroup requested the SAME 18 KiB per slice from L2 (144 KiB per unit and CU next to 41 KiB
+// of input): the knock-outs of tools/ks_knockouts.sh put that stream, not MFMA or LDS, at 25 - 35 % of the kernel's time.
+#ifndef KS_WLDS
+#define KS_WLDS 1
+#endif
+#ifndef KS_WLDS_CT
+#define KS_WLDS_CT 2      // widest workgroup (in 16-channel tiles) that takes the LDS path
+#endif
+constexpr int KS_WBUF_MAX = 2 * 18 * 1024;      // CT = 2: 36 KiB per weight buffer
 
 __device__ __forceinline__ void ks_dma_1k(const void* gptr, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory");
@@ -75,6 +87,8 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
   constexpr int FRW = NTX * 2, NF = NYY * FRW;        // fragments per haloed row (dx x K-chunk), per unit
   constexpr int NPIECE = (KS_CH + 7) / 8;             // DMA pieces per wave and unit
   constexpr int NWL = NTY * NTX * 2;                  // weight fragments per slice
+  constexpr bool WLDS = KS_WLDS && MODE == 0 && CT <= KS_WLDS_CT;      // the slice's weights through LDS (shared by the workgroup) instead of per-wave registers loads
+  constexpr int WCH = CT * 18, NWP = WLDS ? (WCH + 7) / 8 : 0, WBUF = WCH * 1024;      // 1-KiB weight chunks per slice (tap x 8-row group); pieces per wave
   constexpr int PW = KS_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -106,7 +120,9 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
       const int gy = t.y0 - 1 + py, gx = t.x0 - 1 + px, ch = sl * 64 + ls * 8;
       const bool ok = t.live && ch < a.cinv && pix < PW * KS_PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       const char* src = X + ((((long)t.b * a.H + gy) * a.W + gx) * a.ldx + ch) * 2;
+#ifndef KS_EXP_NO_DMA      // (KS_EXP_*: knock-outs for tools/build_variant.sh experiment builds, never the shipped library)
       ks_dma_1k(ok ? src : zero, buf + id * 1024);
+#endif
     }
   };
   // ---- this wave's output: channel tile (wave % CT) of block blk, rows RH * (wave / CT) .. + RH - 1
@@ -117,17 +133,41 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
   const int nrow = ch0 + li, c4 = ch0 + q * 4;
   const T* Wp = reinterpret_cast<const T*>(a.wp);
   const T* zw = reinterpret_cast<const T*>(&dd_zero16_v);
+  // ---- WLDS: weight chunk id = k*8 + wave = tap * (CT*2) + g holds rows g*8 + r of the block's CT*16 output channels, K-slice sl (64 values = 8 slots
+  //      of 16 bytes), slot (lane & 7) of row r holding logical slot (lane & 7) ^ r like the input tile: a fragment read (16 rows x one slot) is conflict-free
+  const unsigned wlds_base = lds_base + 2 * KS_BUF;
+  auto wpiece = [&](int k, int sl, unsigned wbuf) {
+    const int id = k * 8 + wave;
+    if (WLDS && id < WCH) {      // wave-uniform
+      int rr = r;
+      asm volatile("" : "+v"(rr));
+      const int tap = id / (CT * 2), g = id - tap * (CT * 2);
+      const int row = a.n0 + blk * (CT * 16) + g * 8 + rr, k0 = sl * 64 + ((lane & 7) ^ rr) * 8;
+      const bool ok = row < a.n_pad && k0 < a.k_pad;
+      ks_dma_1k(ok ? reinterpret_cast<const char*>(Wp + ((long)tap * a.n_pad + row) * a.k_pad + k0) : zero, wbuf + id * 1024);
+    }
+  };
+  const unsigned wrd = wlds_base + ((wave % CT) * 16 + li) * 128 + ((q ^ (li & 7)) << 4);      // this lane's 16 bytes of (tap 0, K-chunk 0) in weight buffer 0
   // weight fragment w of slice sl: w = (ty * NTX + tx) * 2 + kc
   auto load_w = [&](int w, int sl) {
     const int kc = w & 1, tx = (w >> 1) % NTX, ty = (w >> 1) / NTX;
     const int srct = ks_src(PY, TY0 + ty) * 3 + ks_src(PX, TX0 + tx);
     const int k0 = sl * 64 + kc * 32 + q * 8;
     const bool ok = active && nrow < a.n_pad && k0 < a.k_pad;
+#ifdef KS_EXP_NO_W
+    return uint4{(unsigned)k0, (unsigned)srct, 0u, 0u};
+#else
     return *reinterpret_cast<const uint4*>(ok ? Wp + ((long)srct * a.n_pad + nrow) * a.k_pad + k0 : zw);
+#endif
   };
   uint4 wA[NWL], wB[NWL];
+  if constexpr (WLDS) {
 #pragma unroll
-  for (int w = 0; w < NWL; ++w) wA[w] = load_w(w, 0);
+    for (int k = 0; k < NWP; ++k) wpiece(k, 0, wlds_base);
+  } else {
+#pragma unroll
+    for (int w = 0; w < NWL; ++w) wA[w] = load_w(w, 0);
+  }
   float bv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) bv[e] = (!GATHER && a.bias && active && c4 + e < a.nbias) ? a.bias[c4 + e] : 0.f;
@@ -149,18 +189,29 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
   // one unit: multiply slice `sl` of tile `cur` with the weights wc; meanwhile request the next unit's input tile and its weights (into wn)
   auto unit = [&](uint4 (&wc)[NWL], uint4 (&wn)[NWL]) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA chunks and weight fragments of this unit have landed (and its stores)
+#ifndef KS_EXP_NO_BAR
     __syncthreads();
+#endif
     const bool last = sl == NS - 1;
     const int nsl = last ? 0 : sl + 1;
     // (component-wise: a select between whole structs lives in scratch memory)
     const KsTile adv = tile_at(tile + a.ksplit);
     KsTile nxt;
     nxt.b = last ? adv.b : cur.b; nxt.y0 = last ? adv.y0 : cur.y0; nxt.x0 = last ? adv.x0 : cur.x0; nxt.live = last ? adv.live : cur.live;
-    const unsigned nbuf = lds_base + (sel ^ 1) * KS_BUF;
+    const unsigned nbuf = lds_base + (sel ^ 1) * KS_BUF, nwbuf = wlds_base + (sel ^ 1) * WBUF;
     if (!active) {
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) piece(k, nxt, nsl, nbuf);
+#pragma unroll
+      for (int k = 0; k < NWP; ++k) wpiece(k, nsl, nwbuf);
     } else {
+      // WLDS: this unit's 18 fragments come from the workgroup's copy (landed before the barrier above): the six of tap row 0 now, tap row t + 1 during
+      // the fragment steps of haloed row t, a full row ahead of its first use (all 18 up front put 23 LDS reads in front of every unit's first MFMA)
+      auto wread = [&](int w) { return ks_lds16((wrd + sel * WBUF + (w >> 1) * (CT * 2048)) ^ ((w & 1) << 6)); };
+      if constexpr (WLDS) {
+#pragma unroll
+        for (int w = 0; w < FRW; ++w) wc[w] = wread(w);
+      }
       if (sl == 0) {
 #pragma unroll
         for (int y = 0; y < RH; ++y) acc[y] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
@@ -169,7 +220,11 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
       uint4 ring[RING];
       auto frag = [&](int f) {
         const int yy = TY0 + f / FRW, j = f % FRW, dx = TX0 + j / 2, kc = j & 1, C = yy * PW + dx;
+#ifdef KS_EXP_NO_LDS
+        return uint4{d0[C & 7], (unsigned)kc, 0u, 0u};
+#else
         return ks_lds16((d0[C & 7] ^ (kc << 6)) + C * DD_LDS_ROW);
+#endif
       };
 #pragma unroll
       for (int f = 0; f < AHEAD && f < NF; ++f) ring[f] = frag(f);
@@ -179,22 +234,35 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
         for (int j = 0; j < FRW; ++j) {
           const int f = yi * FRW + j, txi = j / 2, kc = j & 1;
           if (f + AHEAD < NF) ring[(f + AHEAD) % RING] = frag(f + AHEAD);
+          if constexpr (WLDS) {
+            if (yi + 1 < NTY) wc[(yi + 1) * FRW + j] = wread((yi + 1) * FRW + j);
+          }
           {      // the next unit's DMA pieces and weight fragments, spread evenly over the NF steps: piece k goes with step (k NF) / NPIECE.
                  // (A narrow wave -- 2 output rows, one tap -- has FEWER steps than pieces: several pieces per step, none may be dropped.)
             constexpr int SPAN = NF * KS_DMA_SPAN / 8 > NPIECE ? NF * KS_DMA_SPAN / 8 : NF;
 #pragma unroll
             for (int k = 0; k < NPIECE; ++k)
               if ((k * SPAN) / NPIECE == f) piece(k, nxt, nsl, nbuf);
+            if constexpr (WLDS) {
 #pragma unroll
-            for (int w = 0; w < NWL; ++w)
-              if ((w * NF) / NWL == f) wn[w] = load_w(w, nsl);
+              for (int k = 0; k < NWP; ++k)
+                if ((k * NF) / NWP == f) wpiece(k, nsl, nwbuf);
+            } else {
+#pragma unroll
+              for (int w = 0; w < NWL; ++w)
+                if ((w * NF) / NWL == f) wn[w] = load_w(w, nsl);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           const uint4 b = IN_RELU ? relu16<T>(ring[f % RING]) : ring[f % RING];
 #pragma unroll
           for (int tyi = 0; tyi < NTY; ++tyi) {
             const int y = yi - tyi;
+#ifdef KS_EXP_NO_MFMA
+            if (y >= 0 && y < RH) acc[y][0] += __uint_as_float(wc[(tyi * NTX + txi) * 2 + kc].x ^ b.x);
+#else
             if (y >= 0 && y < RH) acc[y] = mma16<T>(wc[(tyi * NTX + txi) * 2 + kc], b, acc[y]);
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -344,12 +412,13 @@ extern "C" int dd_conv3x3_ks(const dd_conv_ks_args* a, dd_stream stream) {
     }
   for (int i = ns; i < KS_MAX_SUB; ++i) m.sub[i] = KsSub{0, 1, 0, 0, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = 2 * (size_t)KS_BUF + (KS_WLDS ? 2 * (size_t)KS_WBUF_MAX : 0);      // two input buffers + two weight buffers (narrow workgroups)
   if (a->dtype == DD_BF16) {
     dd_allow_max_lds(reinterpret_cast<const void*>(conv_ks_kernel<bf16_t>));
-    hipLaunchKernelGGL(conv_ks_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)ns), dim3(512), 2 * (size_t)KS_BUF, s, m);
+    hipLaunchKernelGGL(conv_ks_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)ns), dim3(512), smem, s, m);
   } else {
     dd_allow_max_lds(reinterpret_cast<const void*>(conv_ks_kernel<f16_t>));
-    hipLaunchKernelGGL(conv_ks_kernel<f16_t>, dim3((unsigned)gx, (unsigned)ns), dim3(512), 2 * (size_t)KS_BUF, s, m);
+    hipLaunchKernelGGL(conv_ks_kernel<f16_t>, dim3((unsigned)gx, (unsigned)ns), dim3(512), smem, s, m);
   }
   DD_LAUNCH_CHECK();
   return DD_OK;
