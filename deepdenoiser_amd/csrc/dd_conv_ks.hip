@@ -45,7 +45,7 @@ constexpr int KS_PW = DD_TILE + 2, KS_PH = DD_TILE + 2, KS_CH = (KS_PW * KS_PH +
 // Round 5: a workgroup of <= 32 output channels (CT = 1, 2) shares a K-slice's weights through LDS -- 9 taps x CT x 16 rows x 128 bytes arrive by
 // LDS-DMA once per workgroup, double buffered behind the two input buffers, and every wave reads its 18 fragments from there at the top of a unit.
 // With the register path all eight waves of a 16-channel workgroup requested the SAME 18 KiB per slice from L2 (144 KiB per unit and CU next to 41 KiB
-// of input): the knock-outs of tools/ks_knockouts.sh put that stream, not MFMA or LDS, at 25 - 35 % of the kernel's time.
+// of input; every mode's own tap set): the knock-outs of tools/ks_knockouts.sh put that stream, not MFMA or LDS, at 25 - 35 % of the kernel's time.
 #ifndef KS_WLDS
 #define KS_WLDS 1
 #endif
@@ -87,8 +87,8 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
   constexpr int FRW = NTX * 2, NF = NYY * FRW;        // fragments per haloed row (dx x K-chunk), per unit
   constexpr int NPIECE = (KS_CH + 7) / 8;             // DMA pieces per wave and unit
   constexpr int NWL = NTY * NTX * 2;                  // weight fragments per slice
-  constexpr bool WLDS = KS_WLDS && MODE == 0 && CT <= KS_WLDS_CT;      // the slice's weights through LDS (shared by the workgroup) instead of per-wave registers loads
-  constexpr int WCH = CT * 18, NWP = WLDS ? (WCH + 7) / 8 : 0, WBUF = WCH * 1024;      // 1-KiB weight chunks per slice (tap x 8-row group); pieces per wave
+  constexpr bool WLDS = KS_WLDS && CT <= KS_WLDS_CT;      // the slice's weights through LDS (shared by the workgroup) instead of per-wave register loads
+  constexpr int WCH = NTY * NTX * CT * 2, NWP = WLDS ? (WCH + 7) / 8 : 0, WBUF = WCH * 1024;      // 1-KiB weight chunks per slice (tap x 8-row group); pieces per wave
   constexpr int PW = KS_PW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -141,10 +141,11 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
     if (WLDS && id < WCH) {      // wave-uniform
       int rr = r;
       asm volatile("" : "+v"(rr));
-      const int tap = id / (CT * 2), g = id - tap * (CT * 2);
+      const int tap = id / (CT * 2), g = id - tap * (CT * 2), ty = tap / NTX, tx = tap - ty * NTX;      // tap: index into THIS mode's tap set
+      const int srct = ks_src(PY, TY0 + ty) * 3 + ks_src(PX, TX0 + tx);
       const int row = a.n0 + blk * (CT * 16) + g * 8 + rr, k0 = sl * 64 + ((lane & 7) ^ rr) * 8;
       const bool ok = row < a.n_pad && k0 < a.k_pad;
-      ks_dma_1k(ok ? reinterpret_cast<const char*>(Wp + ((long)tap * a.n_pad + row) * a.k_pad + k0) : zero, wbuf + id * 1024);
+      ks_dma_1k(ok ? reinterpret_cast<const char*>(Wp + ((long)srct * a.n_pad + row) * a.k_pad + k0) : zero, wbuf + id * 1024);
     }
   };
   const unsigned wrd = wlds_base + ((wave % CT) * 16 + li) * 128 + ((q ^ (li & 7)) << 4);      // this lane's 16 bytes of (tap 0, K-chunk 0) in weight buffer 0
