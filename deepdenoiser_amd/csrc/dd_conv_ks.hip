@@ -49,6 +49,9 @@ constexpr int KS_PW = DD_TILE + 2, KS_PH = DD_TILE + 2, KS_CH = (KS_PW * KS_PH +
 #ifndef KS_WLDS
 #define KS_WLDS 1
 #endif
+#ifndef KS_GATHER_EARLY
+#define KS_GATHER_EARLY 1      // gather epilogue operands requested at the top of the tile's last unit (narrow forms)
+#endif
 #ifndef KS_WLDS_CT
 #define KS_WLDS_CT 2      // widest workgroup (in 16-channel tiles) that takes the LDS path
 #endif
@@ -145,7 +148,9 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
       const int srct = ks_src(PY, TY0 + ty) * 3 + ks_src(PX, TX0 + tx);
       const int row = a.n0 + blk * (CT * 16) + g * 8 + rr, k0 = sl * 64 + ((lane & 7) ^ rr) * 8;
       const bool ok = row < a.n_pad && k0 < a.k_pad;
+#ifndef KS_EXP_NO_W
       ks_dma_1k(ok ? reinterpret_cast<const char*>(Wp + ((long)srct * a.n_pad + row) * a.k_pad + k0) : zero, wbuf + id * 1024);
+#endif
     }
   };
   const unsigned wrd = wlds_base + ((wave % CT) * 16 + li) * 128 + ((q ^ (li & 7)) << 4);      // this lane's 16 bytes of (tap 0, K-chunk 0) in weight buffer 0
@@ -217,6 +222,23 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
 #pragma unroll
         for (int y = 0; y < RH; ++y) acc[y] = f32x4_t{bv[0], bv[1], bv[2], bv[3]};
       }
+      // GATHER on the narrow forms (registers to spare since the weights come through LDS): the mask and the stored gradient of the tile's rows are
+      // requested HERE, a whole unit of MFMAs ahead of the epilogue that needs them -- with a short reduction (one slice: the 16 -> 16 gathers of the
+      // light Tiramisu) a unit was ~1 us of MFMAs followed by an exposed ~2 us round trip for these two loads.
+      constexpr bool EARLY = GATHER && WLDS && KS_GATHER_EARLY;
+      uint2 emv[EARLY ? RH : 1], eov[EARLY ? RH : 1];
+      if constexpr (EARLY) {
+        const bool has_mask = a.mask != nullptr;
+        const bool col_ok = ch_ok && cur.x0 + li < a.W;
+        const T* mp = reinterpret_cast<const T*>(a.mask) + (((long)cur.b * a.H + cur.y0 + half * RH) * a.W + cur.x0 + li) * a.ldmask + c4;
+        const T* op = Y + (((long)cur.b * a.Hout + cur.y0 + half * RH) * a.Wout + cur.x0 + li) * a.ldy + c4;      // (GATHER: output on the input grid)
+#pragma unroll
+        for (int y = 0; y < RH; ++y) {
+          const bool ok = last && col_ok && cur.y0 + half * RH + y < a.H;
+          emv[y] = (ok && has_mask) ? *reinterpret_cast<const uint2*>(mp + y * (long)a.W * a.ldmask) : uint2{0u, 0u};
+          eov[y] = (ok && a.accum) ? *reinterpret_cast<const uint2*>(op + y * yrow) : uint2{0u, 0u};
+        }
+      }
       constexpr int RING = 6, AHEAD = RING - 1;
       uint4 ring[RING];
       auto frag = [&](int f) {
@@ -283,6 +305,7 @@ __device__ __forceinline__ void conv_ks_body(const KsP& a, char* smem, int block
 #pragma unroll
             for (int y = 0; y < GB; ++y) {
               const bool ok = col_ok && cur.y0 + half * RH + yb + y < a.H;
+              if constexpr (EARLY) { mv[y] = emv[yb + y]; ov[y] = eov[yb + y]; continue; }
               mv[y] = (ok && has_mask) ? *reinterpret_cast<const uint2*>(mp + (yb + y) * mrow) : uint2{0u, 0u};
               ov[y] = (ok && a.accum) ? *reinterpret_cast<const uint2*>(yp + (yb + y) * yrow) : uint2{0u, 0u};
             }
