@@ -51,6 +51,10 @@ python tools/example_profile.py 8 > $out/example_profile.txt 2>&1
 ( timeout 600 python tools/ab_bench.py "default:" "loss_unfused:DD_FUSE_LOSS_INVERT=0,DD_LOSS_SIMPLE=0,DD_LOSS_GENERAL=0" --repeat 2;
   timeout 600 python tools/ab_bench.py "frames_in_place:" "extract_tiles:DD_FRAME_INPUT=0" --inference --repeat 2 ) > $out/ab_round5.txt 2>&1
 [ -f tools/exp/libdd_natpitch.so ] && ( timeout 400 python tools/ab_bench.py "padded_strips:" "natural_pitch:DD_LIB=tools/exp/libdd_natpitch.so" --repeat 2 ) >> $out/ab_round5.txt 2>&1
+# round 5, last part: the issue-level counter rows of the cfg-3 kernels (conv_ks, stacked weight gradients) and the per-layer times of the Tiramisu shapes
+SQT_CMD="python tools/cfg3_step.py heavy 8 2" SQT_OUT=$out/sq_table_cfg3_heavy.txt bash tools/pmc_sq_table.sh conv_ks wgrad conv_igemm_ws conv_pw conv_rw > /dev/null 2>&1
+SQT_CMD="python tools/cfg3_step.py light 8 2" SQT_OUT=$out/sq_table_cfg3_light.txt bash tools/pmc_sq_table.sh conv_ks wgrad conv_igemm_ws conv_pw conv_rw > /dev/null 2>&1
+( python tools/ks_shape_bench.py; echo "== DD_CONV_KS_THIN=1"; DD_CONV_KS_THIN=1 python tools/ks_shape_bench.py ) 2>&1 | grep -v amdgpu.ids > $out/ks_shape_bench.txt
 python tools/cfg3_launches.py light 8 > $out/cfg3_light_launches.txt 2>&1
 python tools/cfg3_launches.py heavy 8 > $out/cfg3_heavy_launches.txt 2>&1
 rm -rf $out/prof $out/prof_inf $out/prof_cfg3 $out/prof_cfg3l $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES
