@@ -181,7 +181,7 @@ def _timed_steps(trainer, steps, warmup):
 
 def _conv_roofline(prog, peak):
     """MFMA conv launches of one step of `prog` (HIP events per launch): algorithmic FLOPs / their time, and the step's launch-time total."""
-    times, launches = prog.profile_ops(repeats=2, detail=True)
+    times, launches = prog.profile_ops(repeats=3, detail=True)
     convs = {k: v for k, v in times.items() if k in ("conv_igemm", "conv_bwd", "conv_wgrad", "convt") and v[1] > 0}
     ms, fl = sum(v[1] for v in convs.values()), sum(v[2] for v in convs.values())
     roof = {"bound": "mfma", "kernel": "all MFMA conv launches of the step", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -224,7 +224,7 @@ def extras(device, B, H, W):
         pred = Predictor(arch, tile_size=128, tile_overlap_size=14, tiles_per_batch=256)
         pred.prepare(1080, 1920)
         prog = pred._plans[(1080, 1920)][1]
-        times = prog.profile_ops(repeats=2)
+        times = prog.profile_ops(repeats=3)
         fl = times.get("conv_igemm", (0, 0.0, 0.0))[2]
         ms_conv = times.get("conv_igemm", (0, 1e-9, 0.0))[1]
         ms_all = sum(v[1] for v in times.values())

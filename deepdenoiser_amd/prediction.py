@@ -108,7 +108,7 @@ class Predictor:
         direct = (prog.fused_input and os.environ.get("DD_FRAME_INPUT", "1") != "0"
                   and all(frame[Naming.source_feature_name(f.name, index=0)].shape[2] == f.number_of_channels for f in feats))
         if direct:
-            if prog.frame_input is None:
+            if prog.frame_input != (H, W):      # (programs are cached per (tiles per batch, tile): another frame size may share this one)
                 prog.enable_frame_input(H, W)
             prog.set_frame_sources({f.name: frame[Naming.source_feature_name(f.name, index=0)] for f in feats})
         elif prog.frame_input is not None:      # (programs are cached per architecture: an earlier frame may have been read in place)

@@ -209,6 +209,49 @@ def test_frame_input_read_in_place_is_bit_identical_to_extracted_tiles(dtype, mo
     assert pred._plans[(H, W)][1].frame_input is None
 
 
+def test_frame_input_state_of_a_shared_program_follows_the_frame_and_the_tile_path():
+    """programs are cached per (tiles per batch, tile) and shared.  Two frame sizes that map to the same program must each be read
+    with their own (H, W) (the second one used to keep the first one's and fail the shape check), and Architecture.predict() on that program
+    after a predict_frame() must read the tile buffers again, not the previous frame's device pointers."""
+    _need_gpu()
+    from deepdenoiser_amd.architecture import Architecture
+    from deepdenoiser_amd.prediction import Predictor
+    aj = configs.cfg2_unet_kpcn(filters=(16, 24, 32), convs=2)
+    T, O = 64, 10
+    key = Naming.feature_prediction_name("Emission")
+    g = torch.Generator().manual_seed(11)
+    arch = Architecture(aj, device="cuda", dtype="f32", seed=4)
+
+    def make_frame(H, W):
+        return {Naming.source_feature_name(f.name, index=0): torch.randn(H, W, f.number_of_channels, generator=g).abs().cuda()
+                for f in arch.feature_predictions + arch.auxiliary_features}
+    fa, fb = make_frame(60, 100), make_frame(100, 60)                     # two tiles each: the same (2, 64, 64) program
+    pred = Predictor(arch, tile_size=T, tile_overlap_size=O, tiles_per_batch=2)
+    a = pred.predict_frame(fa)[key].clone()
+    b = pred.predict_frame(fb)[key].clone()
+    pa, pb = pred._plans[(60, 100)][1], pred._plans[(100, 60)][1]
+    assert pa is pb and pa.frame_input == (100, 60)
+    a2 = pred.predict_frame(fa)[key].clone()
+    assert tuple(a.shape) == (60, 100, 3) and tuple(b.shape) == (100, 60, 3) and torch.equal(a, a2)
+    # the extraction path (fresh predictor, fresh program state) is the reference for both
+    import os
+    os.environ["DD_FRAME_INPUT"] = "0"
+    try:
+        ref = Predictor(arch, tile_size=T, tile_overlap_size=O, tiles_per_batch=2)
+        assert torch.equal(ref.predict_frame(fa)[key], a) and torch.equal(ref.predict_frame(fb)[key], b)
+    finally:
+        del os.environ["DD_FRAME_INPUT"]
+    # tile path on the shared program, before and after a frame was read in place through it
+    tiles = {k: torch.stack([v[:T, :T], v[-T:, -T:]]) for k, v in make_frame(80, 80).items()}
+    fresh = Architecture(aj, device="cuda", dtype="f32", seed=4)
+    want = fresh.predict(tiles)[0][key].clone()
+    pred.predict_frame(fb)
+    assert pa.frame_input is not None
+    got = arch.predict(tiles)[0][key]
+    assert pa.frame_input is None and torch.equal(got, want)
+    assert torch.equal(pred.predict_frame(fa)[key], a)                      # ... and back
+
+
 def test_predictor_repacks_the_weights_when_they_changed_and_only_then(monkeypatch):
     """A frame sequence runs on fixed weights: the Predictor skips dd_pack_weights_batched while ParamStore.state_key() stands still (round 5) and
     must notice every way the values can change -- load_list (torch writes) and an optimizer step (a launch writing through the raw pointer)."""
