@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["dd_conv_igemm.hip", "dd_conv_wgrad.hip", "dd_pointwise.hip", "dd_compose.hip", "dd_head.hip", "dd_conv_bwd.hip", "dd_convt.hip",
-           "dd_conv_rw.hip", "dd_conv_ks.hip", "dd_conv_pw.hip", "dd_conv_pair.hip", "dd_compose_stream.hip", "dd_compose_stream_bwd.hip"]
+           "dd_conv_rw.hip", "dd_conv_ks.hip", "dd_conv_pw.hip", "dd_conv_pair.hip", "dd_conv_bwd96.hip", "dd_compose_stream.hip", "dd_compose_stream_bwd.hip"]
 VERSION_SRC = "dd_version.hip"
 HEADERS = ["dd_common.h", "dd_compose_stream.h", os.path.join("..", "..", "include", "dd_hip.h")]
 LIB = os.path.join(HERE, "libdd_hip.so")
@@ -25,6 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # compose backward that wrote 15x its algorithmic bytes to scratch).  A build in which one of them reports a non-zero ScratchSize is refused.
 NO_SCRATCH = {
     "dd_conv_bwd.hip": ("conv_bwd_kernel", "conv_bwd_multi_kernel"),
+    "dd_conv_bwd96.hip": ("conv_bwd96_kernel",),
     "dd_pointwise.hip": ("kpcn_fwd_kernel", "kpcn_bwd_kernel", "assemble_input_kernel"),
     "dd_convt.hip": ("convt_bwd_kernel", "convt_fwd_kernel"),
     "dd_conv_rw.hip": ("conv_rw_kernel", "conv_rw8_kernel"),

@@ -447,6 +447,7 @@ int launch_bwd(const BwdP& p, hipStream_t stream) {
 }  // namespace
 
 static int bwd_fill(BwdP& p, const dd_conv_bwd_args* a);
+int dd_conv_bwd96_launch(const dd_conv_bwd_args* a, hipStream_t stream);      // csrc/dd_conv_bwd96.hip
 
 // weight / bias gradients only (dx = NULL) of up to BW_MAX_MULTI layers on the same [B, H, W] grid, one launch
 extern "C" int dd_conv3x3_bwd_multi(const dd_conv_bwd_args* a, int n, dd_stream stream) {
@@ -509,6 +510,10 @@ extern "C" int dd_conv3x3_bwd(const dd_conv_bwd_args* a, dd_stream stream) {
   if (int rc = bwd_fill(p, a)) return rc;
   const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // 65 - 96 output channels with a data gradient (round 6): one launch of the kernel that gives a workgroup a 32-channel third of the input
+  // against all output channels (csrc/dd_conv_bwd96.hip); DD_CONV_BWD96=0: one launch per 64 output channels below
+  static const bool bwd96 = [] { const char* e = getenv("DD_CONV_BWD96"); return !(e && e[0] == '0'); }();
+  if (bwd96 && a->dx && a->cout > 64 && a->cout <= 96) return dd_conv_bwd96_launch(a, s);
   // Without a data gradient the output-channel blocks are workgroup columns of ONE launch.  With one, a launch covers 64 output channels (its
   // data-gradient role sums over all of them): wider layers run as consecutive launches, the later ones accumulating into dx (the ReLU mask
   // distributes over the partial sums; dx is rounded once more per extra launch, as with any accumulated gradient).

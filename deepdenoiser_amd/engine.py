@@ -538,7 +538,10 @@ class Graph:
             # one pass over dy and x for both gradients (3x3, <= 64 output channels, bf16 / f16 storage): csrc/dd_conv_bwd.hip
             # (more than 64 output channels: dd_conv3x3_bwd runs one launch per 64 of them, each re-reading x and re-writing dx -- measured
             #  slower than the register-weight data gradient + the weight-gradient role: 4.80 against 4.10 ms per step; opt-in only)
-            wide_ok = layer.cout <= 64 or (x.requires_grad and os.environ.get("DD_FUSE_CONV_BWD_WIDE", "0") != "0")
+            # (round 6: 65 - 96 output channels with a data gradient have a fused kernel of their own, csrc/dd_conv_bwd96.hip: a 32-channel third
+            #  of the input per workgroup against all output channels; DD_CONV_BWD96=0 restores the two-launch path)
+            wide_ok = (layer.cout <= 64 or (x.requires_grad and layer.cout <= 96 and os.environ.get("DD_CONV_BWD96", "1") != "0")
+                       or (x.requires_grad and os.environ.get("DD_FUSE_CONV_BWD_WIDE", "0") != "0"))
             wide_ok = wide_ok and x.B * x.H * x.W < (1 << 23)      # dd_conv3x3_bwd's own limit (linear pixel index in the DMA swizzle): larger problems split
             if (layer.k == 3 and self.dtype in ("bf16", "f16") and wide_ok and not in_relu and (x.requires_grad or layer.cin >= 16)
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):

@@ -192,6 +192,13 @@ FUSED_BWD_CASES = [
     (32, 64, 16, 16, False, 2),       # no ReLU mask on the input
     (8, 16, 40, 24, True, 1),         # narrow: one tile of each kind, 32-channel K
     (72, 40, 33, 17, True, 2),        # nothing a multiple of 16
+    # 65 - 96 output channels (round 6, csrc/dd_conv_bwd96.hip: a 32-channel third of the input per workgroup against all output channels)
+    (96, 96, 32, 32, True, 2),        # the U-Net's 64 x 64 level: three input blocks, every wave of both roles busy
+    (192, 96, 20, 28, True, 2),       # decoder conv over the skip concat: six input blocks, ragged tiles
+    (64, 96, 16, 48, True, 3),        # first conv of the level (two input blocks)
+    (96, 80, 33, 17, False, 2),       # the last output-channel tile of one parity is empty; no mask
+    (40, 72, 9, 35, True, 1),         # nothing a multiple of 16: half-empty input block, ragged everything
+    (24, 96, 48, 16, True, 2),        # one input block with an idle channel tile... (24 = 16 + 8)
 ]
 
 
