@@ -32,6 +32,16 @@
 #include "dd_common.h"
 #include <type_traits>
 
+#ifndef B96_RING
+#define B96_RING 6          // data-gradient role: ring of dy fragments (RING - 1 steps ahead)
+#endif
+#ifndef B96_BA
+#define B96_BA 2            // weight-gradient role: new aligned dy fragments are requested this many steps ahead
+#endif
+#ifndef B96_DMA_SPAN
+#define B96_DMA_SPAN 8      // eighths of a tile's fragment steps over which the data-gradient waves issue the next tile's DMA pieces
+#endif
+
 namespace {
 
 struct Bw96P {
@@ -104,15 +114,26 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int PW = B96_PW, ROW = B96_ROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroup -> (input block cb, tile sequence ks).  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.  The
+  // nblk workgroups of ONE tile sequence read the same haloed dy tiles at the same time: they sit on one XCD (consecutive slots of it), so dy comes
+  // out of HBM / the infinity cache once per sequence, not once per input block (192 -> 96: six blocks; measured 393 -> see DESIGN 8.1).  Sequences
+  // beyond the last multiple of 8 (85 = 80 + 5 for three blocks on 256 CUs) fill the remaining workgroups in plain order.  Iteration i of a sequence
+  // covers tile i*ksplit + tile0; the sequences of one XCD take a contiguous run of tiles (neighbouring tiles share halo rows and columns).
   const int block = blockIdx.x;
-  const int cb = block / a.ksplit, ks = block - cb * a.ksplit;      // 32-channel input block of this workgroup; its index among the block's workgroups
+  const int ks_al = a.ksplit & ~7, n_al = a.nblk * ks_al;
+  int cb, tile0;
+  if (block < n_al) {
+    const int xcd = block & 7, slot = block >> 3, m = slot / a.nblk;
+    cb = slot - m * a.nblk;
+    tile0 = xcd * (ks_al >> 3) + m;
+  } else {
+    const int r = block - n_al, m = r / a.nblk;
+    cb = r - m * a.nblk;
+    tile0 = ks_al + m;
+  }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int per_img = a.tiles_y * a.tiles_x;
   const int total_tiles = a.B * per_img;
-  // tile sequence as in csrc/dd_conv_bwd.hip: the workgroups of one XCD (blockIdx % 8) take contiguous runs of tiles (shared dy halos meet in one L2)
-  const int xcd_n = (a.ksplit & 7) == 0 ? 8 : 1;
-  const int per_xcd = a.ksplit / xcd_n;
-  const int tile0 = (ks % xcd_n) * per_xcd + ks / xcd_n;
 
   if (wave < 4) {
     // ================================================================== data-gradient role: wave = (input-channel tile cit, tile half)
@@ -145,8 +166,16 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
       asm volatile("" : "+v"(rr), "+v"(xl), "+v"(lsv));
       if (k < QPC) {
         const int c = wr * QPC + k;            // tile row c, its 16 pixels
+#ifdef B96_EXP_NO_DMA
+        const bool ok = false;      // (knock-out builds, tools/b96_knockouts.sh: every piece comes from the zero page)
+#else
         const bool ok = o.live && x_ok && o.y0 + c < a.H && o.x0 + rr < a.W;
+#endif
+#ifdef B96_EXP_CONTIG      // (knock-out build: the same bytes per tile as 1-KiB contiguous reads -- 8 cache lines per instruction instead of 16 half lines)
+        b96_dma_1k(reinterpret_cast<const char*>(X) + ((((long)(o.b * per_img) + c) * 1024 + lane * 16) % ((long)a.B * a.H * a.W * a.ldx * 2 - 1024)), buf + B96_P_BYTES + c * 1024);
+#else
         b96_dma_1k(ok ? o.q + (c * x_row + xl) : zero, buf + B96_P_BYTES + c * 1024);
+#endif
       } else {
         const int c = (k - QPC) * 4 + wr;      // chunk c of the 63: image kc = c / 21, pixels (c % 21)*16 + r of the 18 x 18 tile
         if (c < B96_PCH) {                     // wave-uniform
@@ -155,8 +184,16 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
           const int py = (pix * 3641) >> 16, px = pix - py * PW;          // pix / 18 for pix < 400
           const int gy = o.y0 - 1 + py, gx = o.x0 - 1 + px;
           const int dch = kc * 32 + lsv * 8;
+#ifdef B96_EXP_NO_DMA
+          const bool ok = false;
+#else
           const bool ok = o.live && dch < a.coutv && pix < PW * PW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+#endif
+#ifdef B96_EXP_CONTIG
+          b96_dma_1k(reinterpret_cast<const char*>(DY) + (((long)(o.y0 * a.W + o.x0 + (long)o.b * a.H * a.W) * a.lddy * 2 + c * 1024 + lane * 16) % ((long)a.B * a.H * a.W * a.lddy * 2 - 1024)), buf + c * 1024);
+#else
           b96_dma_1k(ok ? o.p + (py * dy_row + px * dy_pix + dch * 2) : zero, buf + c * 1024);
+#endif
         }
       }
     };
@@ -167,7 +204,11 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
     const int li = lane & 15, q = lane >> 4;
     const int ci_row = cb * 32 + cit * 16 + li;                  // A rows: this lane's weight row
     const int c4 = cb * 32 + cit * 16 + q * 4;                   // D rows: the 4 input channels this lane stores
+#ifdef B96_EXP_NO_DROLE
+    const bool active = false;
+#else
     const bool active = a.dx != nullptr && cb * 32 + cit * 16 < a.cin;
+#endif
     uint4 wf[9][B96_NSUB];
     {
       const T* Wd = reinterpret_cast<const T*>(a.wd);
@@ -209,7 +250,7 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
       f32x4_t acc[4];      // output rows y % 4 of this half: row y is complete after haloed row y + 2, written during haloed row y + 3
       uint2 oldv[4], mv[4];
       // 90 fragment steps = 10 haloed rows x 3 column shifts x 3 K-chunks, up to 3 MFMAs each
-      constexpr int RING = 6, AHEAD = RING - 1, HR = DD_TILE / 2 + 2, NF = HR * 9;
+      constexpr int RING = B96_RING, AHEAD = RING - 1, HR = DD_TILE / 2 + 2, NF = HR * 9;
       uint4 ring[RING];
       auto frag = [&](int f) {
         const int yy = f / 9, j = f - 9 * yy, C = yy * PW + j / 3;
@@ -228,7 +269,11 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
           o2.x = pack2<T>(f8[0] + g8[0], f8[1] + g8[1]);
           o2.y = pack2<T>(f8[2] + g8[2], f8[3] + g8[3]);
         }
+#ifdef B96_EXP_NO_STORE
+        if (col_ok && ybase + y < a.H && o2.x == 0x12345678u) *reinterpret_cast<uint2*>(dxp + y * row_stride) = o2;
+#else
         if (col_ok && ybase + y < a.H) *reinterpret_cast<uint2*>(dxp + y * row_stride) = o2;
+#endif
       };
 #pragma unroll
       for (int f = 0; f < AHEAD; ++f) ring[f] = frag(f);
@@ -242,9 +287,10 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
           if (ACCUM && col_ok && ybase + yy < a.H) oldv[yy % 4] = *reinterpret_cast<const uint2*>(dxp + yy * row_stride);
         }
         if constexpr (j == 3 && yy >= 3) write_row(yy - 3);      // (under this row's MFMAs)
-        {      // the NP DMA pieces of the next tile, spread evenly over the NF steps (piece k at step k*NF/NP)
-          constexpr int k0 = (f * NP + NF - 1) / NF;
-          if constexpr (k0 < NP && (k0 * NF) / NP == f) piece(k0, on, sel ^ 1);
+        {      // the NP DMA pieces of the next tile, spread evenly over the first B96_DMA_SPAN / 8 of the NF steps (piece k at step k*SPAN/NP)
+          constexpr int SPAN = NF * B96_DMA_SPAN / 8 > NP ? NF * B96_DMA_SPAN / 8 : NP;
+          constexpr int k0 = (f * NP + SPAN - 1) / SPAN;
+          if constexpr (k0 < NP && (k0 * SPAN) / NP == f) piece(k0, on, sel ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -265,7 +311,11 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
     // ================================================================== weight-gradient role: wave = (input-channel tile cit, output-channel tiles 2j + cg)
     const int w = wave - 4, cit = w & 1, cg = w >> 1;
     const int li = lane & 15, q4 = (lane >> 4) * 4;
+#ifdef B96_EXP_NO_WROLE
+    const bool active = false;
+#else
     const bool active = cb * 32 + cit * 16 < a.cin && cg * 16 < a.cout;
+#endif
     const bool bias_wave = a.db != nullptr && cb == 0 && cit == 0;
     const bool first_row = lane < 32;      // lanes holding the FIRST tile row of a fragment's row pair
     // Fragment addresses (32-bit LDS offsets of the current buffer).  A lane's pixel of a transposed read at tile position C (a compile-time
@@ -303,7 +353,7 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
       if (!active) continue;
       // 72 steps g = 9 s + n: row pair s, (output-channel tile, column shift) n.  Step g: MFMAs of kernel rows 0 and 2 with the OLD / NEW aligned
       // fragment, then the kernel-row-1 MFMA of step g - 1 (its select was written a step earlier).
-      constexpr int NS = 72, BA = 2;      // new fragments are requested BA steps ahead
+      constexpr int NS = 72, BA = B96_BA;      // new fragments are requested BA steps ahead
       uint4 A[9], Bq[BA + 1], M[2], xf[2], xs[2];
 #pragma unroll
       for (int n = 0; n < 9; ++n) A[n] = dy_frag(0, n);
@@ -317,7 +367,12 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
         if constexpr (n == 6 && s + 1 < 8) xs[(s + 1) & 1] = xs_frag(s + 1);
         const uint4 bn = Bq[g % (BA + 1)], an = A[n];
         uint4 m;      // kernel row 1: haloed rows (2s+2 | 2s+1) = (new fragment's first row | old fragment's second row)
+#ifdef B96_EXP_NO_SEL
+        m = bn;
+#else
         m.x = first_row ? bn.x : an.x; m.y = first_row ? bn.y : an.y; m.z = first_row ? bn.z : an.z; m.w = first_row ? bn.w : an.w;
+#endif
+        asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));      // pins the select HERE: left alone hipcc sinks it to its use a step later, two MFMAs in front of the in-place MFMA that reads it
         M[g & 1] = m;
         if (tx == 1 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel 32j + 16cg + li per lane
           float f[8];
@@ -355,7 +410,11 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ci = cb * 32 + cit * 16 + q4 + e;
+#ifdef B96_EXP_NO_FLUSH
+              if (ci < a.cin && acc[t][j][e] == 123.456f) atomicAdd(a.dw + ((long)(8 - t) * a.cin + ci) * a.cout + co, acc[t][j][e]);
+#else
               if (ci < a.cin) atomicAdd(a.dw + ((long)(8 - t) * a.cin + ci) * a.cout + co, acc[t][j][e]);
+#endif
             }
         }
         if (bias_wave) {
