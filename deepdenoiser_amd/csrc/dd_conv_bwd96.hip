@@ -135,6 +135,10 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
   const int per_img = a.tiles_y * a.tiles_x;
   const int total_tiles = a.B * per_img;
 
+#ifdef B96_EXP_STAMP      // (experiment build: cycles a wave spends in the tile-top wait / barrier, printed for two workgroups)
+  long long stamp_vm = 0, stamp_bar = 0, stamp_n = 0;
+  const long long stamp_t0 = __builtin_readcyclecounter();
+#endif
   if (wave < 4) {
     // ================================================================== data-gradient role: wave = (input-channel tile cit, tile half)
     const int wr = wave, cit = wave & 1, half = wave >> 1;
@@ -235,8 +239,17 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 
     int sel = 0;
     for (int tile = tile0; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+#ifdef B96_EXP_STAMP
+      const long long st0 = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of `tile` have landed
+#ifdef B96_EXP_STAMP
+      const long long st1 = __builtin_readcyclecounter();
+#endif
       __syncthreads();                      // ... and everyone's; buffer sel^1 is free
+#ifdef B96_EXP_STAMP
+      stamp_vm += st1 - st0; stamp_bar += __builtin_readcyclecounter() - st1; ++stamp_n;
+#endif
       const Origin on = origin(tile + a.ksplit);
       if (!active) {
 #pragma unroll
@@ -316,7 +329,18 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 #else
     const bool active = cb * 32 + cit * 16 < a.cin && cg * 16 < a.cout;
 #endif
-    const bool bias_wave = a.db != nullptr && cb == 0 && cit == 0;
+    // db[co] = sum over pixels of dy: the centre-tap fragment (kernel row 1, column shift 1 = the unshifted tile) times an all-ones A operand -- one
+    // more MFMA instead of 16 unpack / add instructions.  The 24 (row pair, output-channel tile) units of a tile are dealt round-robin to the
+    // ceil(cin / 16) active waves (input block, input-channel tile) that hold the same output channels, so no wave and no workgroup carries the bias alone
+    // (with the first block's waves summing it on the vector pipe those workgroups ran 8 % longer than the rest: cycle stamps).
+    unsigned bias_mask = 0;
+    if (a.db != nullptr)
+      for (int u = 0; u < 24; ++u) bias_mask |= (unsigned)((u % ((a.cin + 15) >> 4)) == cb * 2 + cit) << u;      // (active waves: ids 0 .. ceil(cin / 16) - 1)
+    const unsigned one2 = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? 0x3F803F80u : 0x3C003C00u;
+    uint4 ones = {one2, one2, one2, one2};
+    // (opaque: a known constant is re-materialised by a v_mov right in front of the in-place MFMA that reads it -- the VALU-write -> MFMA-read
+    //  hazard nothing guards inside inline asm: db came out as NaN.  Unknown to the compiler, the four registers stay live across the launch.)
+    asm volatile("" : "+v"(ones.x), "+v"(ones.y), "+v"(ones.z), "+v"(ones.w));
     const bool first_row = lane < 32;      // lanes holding the FIRST tile row of a fragment's row pair
     // Fragment addresses (32-bit LDS offsets of the current buffer).  A lane's pixel of a transposed read at tile position C (a compile-time
     // constant) is pl + C: address = image + [pl*64 + ((slot ^ key(pl + C)) << 4) + half] + C*64 = pb[C & 7] + C*64.
@@ -339,7 +363,7 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float bsum[3] = {0.f, 0.f, 0.f};
+    f32x4_t bacc[3] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};      // every row = this wave's part of db
     auto x_frag = [&](int s) { return b96_tr_pair(qa[0] + s * 2 * DD_TILE * ROW, qa[1] + s * 2 * DD_TILE * ROW); };
     auto xs_frag = [&](int s) { return b96_tr_pair(qs[0] + s * 2 * DD_TILE * ROW, qs[1] + s * 2 * DD_TILE * ROW); };
     auto dy_frag = [&](int sp, int n) {      // haloed rows (2sp | 2sp+1) at column shift tx = n % 3, output-channel tile j = n / 3 of this wave
@@ -349,7 +373,13 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 
     int sel = 0;
     for (int tile = tile0; tile < total_tiles; tile += a.ksplit, sel ^= 1) {
+#ifdef B96_EXP_STAMP
+      const long long st1 = __builtin_readcyclecounter();
+#endif
       __syncthreads();      // the data-gradient waves' DMA of `tile` has landed (they wait for it before this barrier); buffer sel^1 is free
+#ifdef B96_EXP_STAMP
+      stamp_bar += __builtin_readcyclecounter() - st1; ++stamp_n;
+#endif
       if (!active) continue;
       // 72 steps g = 9 s + n: row pair s, (output-channel tile, column shift) n.  Step g: MFMAs of kernel rows 0 and 2 with the OLD / NEW aligned
       // fragment, then the kernel-row-1 MFMA of step g - 1 (its select was written a step earlier).
@@ -374,17 +404,14 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 #endif
         asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));      // pins the select HERE: left alone hipcc sinks it to its use a step later, two MFMAs in front of the in-place MFMA that reads it
         M[g & 1] = m;
-        if (tx == 1 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel 32j + 16cg + li per lane
-          float f[8];
-          unpack8t<T>(m, f);
-          bsum[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-        }
         __builtin_amdgcn_sched_barrier(0);
         b96_mma_inplace<T>(acc[tx][j], xf[s & 1], an);
         b96_mma_inplace<T>(acc[6 + tx][j], xf[s & 1], bn);
         if constexpr (g > 0) {
           constexpr int gp = g - 1, sp = gp / 9, np = gp - 9 * sp, jp = np / 3, txp = np - 3 * jp;
           b96_mma_inplace<T>(acc[3 + txp][jp], xs[sp & 1], M[gp & 1]);
+          if constexpr (txp == 1)      // centre tap = the unshifted dy tile
+            if ((bias_mask >> (sp * 3 + jp)) & 1u) b96_mma_inplace<T>(bacc[jp], ones, M[gp & 1]);
         }
         A[n] = bn;
         __builtin_amdgcn_sched_barrier(0);
@@ -417,15 +444,15 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 #endif
             }
         }
-        if (bias_wave) {
-          float b = bsum[j];
-          b += __shfl_xor(b, 16);
-          b += __shfl_xor(b, 32);
-          if (lane < 16 && co < a.cout) atomicAdd(a.db + co, b);
-        }
+        if (bias_mask != 0u && lane < 16 && co < a.cout) atomicAdd(a.db + co, bacc[j][0]);
       }
     }
   }
+#ifdef B96_EXP_STAMP
+  if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 100))
+    printf("block %d wave %d: tiles %lld total %lld clk, vmcnt wait %lld, barrier %lld\n", (int)blockIdx.x, wave, stamp_n,
+           (long long)__builtin_readcyclecounter() - stamp_t0, stamp_vm, stamp_bar);
+#endif
   dd_det_end();
 }
 
