@@ -134,8 +134,12 @@ def cpu_baseline(aj, tj, H, W, budget_s=20.0):
                       "(oracle/; TensorFlow itself is not installable); thread count = best of a short sweep" % (n, B, H, W)}
 
 
-def inference_frames(device, dtype, tile, batch, steps, warmup, seed):
-    """Times `steps` full 1080x1920 frames through Predictor on this rank; returns seconds."""
+def inference_frames(device, dtype, tile, batch, steps, warmup, seed, buffer_sets=3, detail=None):
+    """Times `steps` full 1080x1920 frames through Predictor on this rank; returns seconds.  A frame SEQUENCE: the frames rotate through
+    `buffer_sets` distinct sets of device tensors, so the per-frame upload of the input-assembly table runs (with one set it is skipped, as for a
+    caller that refills its tensors in place).  detail (a dict): filled with the device-time breakdown of the timed frames (HIP events inside
+    predict_frame): launches in front of the forward, the forward graph, stitch / recombination behind it, and the idle time BETWEEN frames
+    (device waiting for the host)."""
     from deepdenoiser_amd import configs
     from deepdenoiser_amd.architecture import Architecture
     from deepdenoiser_amd.naming import Naming
@@ -144,16 +148,27 @@ def inference_frames(device, dtype, tile, batch, steps, warmup, seed):
     arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype=dtype, seed=2)
     pred = Predictor(arch, tile_size=tile, tile_overlap_size=14, tiles_per_batch=batch)
     g = torch.Generator().manual_seed(seed)
-    frame = {Naming.source_feature_name(f.name, index=0): torch.randn(H, W, f.number_of_channels, generator=g).abs().to(device)
-             for f in arch.feature_predictions + arch.auxiliary_features}
-    for _ in range(max(1, warmup)):
-        pred.predict_frame(frame)
+    frames = [{Naming.source_feature_name(f.name, index=0): torch.randn(H, W, f.number_of_channels, generator=g).abs().to(device)
+               for f in arch.feature_predictions + arch.auxiliary_features} for _ in range(max(1, buffer_sets))]
+    for i in range(max(2, warmup)):
+        pred.predict_frame(frames[i % len(frames)])
     torch.cuda.synchronize()
+    if detail is not None:
+        pred.profile = []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        pred.predict_frame(frame)
+    for i in range(steps):
+        pred.predict_frame(frames[i % len(frames)])
     torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if detail is not None and pred.profile:
+        ev = pred.profile
+        n = len(ev)
+        detail["before_forward_ms"] = sum(e[0].elapsed_time(e[1]) for e in ev) / n
+        detail["forward_graph_ms"] = sum(e[1].elapsed_time(e[2]) for e in ev) / n
+        detail["stitch_recombine_ms"] = sum(e[2].elapsed_time(e[3]) for e in ev) / n
+        detail["idle_between_frames_ms"] = sum(ev[i][3].elapsed_time(ev[i + 1][0]) for i in range(n - 1)) / max(1, n - 1)
+        detail["frames_timed"] = n
+    return dt
 
 
 def inference_bench(args, device, rank, world):
@@ -216,9 +231,15 @@ def extras(device, B, H, W):
     from deepdenoiser_amd.training import Trainer
     out = {}
     steps = 10
-    dt = inference_frames(device, "f16", 128, 256, steps, 2, 7)
-    out["inference"] = {"metric": "inference MPix/s (1920x1080 frame, 209 halo tiles of 128x128x32ch, fp16 MFMA path, output pixels)",
-                        "value": steps * 1080 * 1920 / dt / 1e6, "unit": "MPix/s", "ms_per_frame": 1e3 * dt / steps, "dtype": "f16", "frames": steps}
+    detail = {}
+    dt = inference_frames(device, "f16", 128, 256, steps, 2, 7, buffer_sets=3, detail=detail)
+    dt_same = inference_frames(device, "f16", 128, 256, steps, 2, 7, buffer_sets=1)
+    out["inference"] = {"metric": "inference MPix/s (1920x1080 frame sequence, 209 halo tiles of 128x128x32ch, fp16 MFMA path, output pixels)",
+                        "value": steps * 1080 * 1920 / dt / 1e6, "unit": "MPix/s", "ms_per_frame": 1e3 * dt / steps, "dtype": "f16", "frames": steps,
+                        "distinct_frames": True, "frame_buffer_sets": 3,
+                        "same_buffers": {"value": steps * 1080 * 1920 / dt_same / 1e6, "ms_per_frame": 1e3 * dt_same / steps,
+                                         "note": "every frame in the same device tensors: the input-assembly table upload is skipped"},
+                        "device_time_ms_per_frame": {k: round(v, 4) if isinstance(v, float) else v for k, v in detail.items()}}
     try:        # roofline of the inference frame: per-launch HIP events of the forward program of the 209-tile batch
         arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype="f16", seed=2)
         pred = Predictor(arch, tile_size=128, tile_overlap_size=14, tiles_per_batch=256)

@@ -26,6 +26,7 @@ class Predictor:
         self.lib = L.load()
         self.use_graph = use_graph
         self._plans, self._graphs = {}, {}
+        self.profile = None          # a list: predict_frame appends (start, before forward, after forward, end) timing events per tile batch / frame
 
     def prepare(self, H, W):
         """Build (and cache) the tile program for an HxW frame; the network parameters exist after this call, so weights are loaded
@@ -113,6 +114,10 @@ class Predictor:
             prog.set_frame_sources({f.name: frame[Naming.source_feature_name(f.name, index=0)] for f in feats})
         elif prog.frame_input is not None:      # (programs are cached per architecture: an earlier frame may have been read in place)
             prog.disable_frame_input()
+        ev = None
+        if self.profile is not None:      # (bench.py: where a frame's time goes on the device, and how long the device waits for the host between frames)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         for oyx, tdev, n in chunks:
             if direct:
                 prog.frame_origins.copy_(oyx, non_blocking=True)
@@ -125,7 +130,11 @@ class Predictor:
                 raw = prog.raw[f.name]
                 L.check(lib.dd_extract_tiles(fr.data_ptr(), H, W, fr.shape[2], f.number_of_channels, raw.data_ptr(), T, raw.shape[3],
                                              oyx.data_ptr(), oyx.shape[0], stream))
+            if ev is not None and oyx is chunks[0][0]:
+                ev[1].record()
             self._forward(prog)
+            if ev is not None and oyx is chunks[-1][0]:
+                ev[2].record()
             tiles = prog.predictions[0]                                  # [NF*Bt, T, T, 3], feature-major
             L.check(lib.dd_stitch(tiles.ptr, T, 3, frames.data_ptr(), H, W, 3, 3, tdev.data_ptr(), n, stream))
         out = {}
@@ -133,6 +142,9 @@ class Predictor:
             if f.is_target and f.load_data:
                 out[Naming.feature_prediction_name(f.name)] = frames[prog.head_index[f.name]][..., :f.number_of_channels]
         self._recombine(prog, frames, out, H * W, stream)
+        if ev is not None:
+            ev[3].record()
+            self.profile.append(ev)
         return out
 
     def _forward(self, prog):

@@ -36,19 +36,27 @@ def _emulated_step(aj, tj, dtype, feats, labels, loss_scale):
     params = oracle.parameters()
     grads = torch.autograd.grad(loss * loss_scale, params, allow_unused=True)
     grads = [torch.zeros_like(p) if g is None else g / loss_scale for g, p in zip(grads, params)]
-    return oracle, [{k: v.detach() for k, v in d.items()} for d in preds], float(loss), grads
+    return oracle, [{k: v.detach() for k, v in d.items()} for d in preds], float(loss.detach()), grads
 
 
-CONDITIONED = [("reused_compose_scales/", "/bias")]      # (name prefix, suffix): near-zero-sum bias gradients, see _compare
+TRAVEL = 0.25      # a tensor whose gradient storage rounding ALONE moves by more than this fraction of its norm is "rounding-dominated", see _compare
 
 
 def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate, grad_max_gate, fwd_median_gate=None, tight=None, conditioned=False):
     """tight = (name prefixes, gate): parameters whose gradient must match at summation-order level (see the bit-faithful test below).
-    conditioned: for the tensors on the allow-list CONDITIONED below (the compose net's bias gradients, sums over every pixel that come out near
-    zero) the error is taken relative to max(|g|, |g - g_plain|), g_plain = the plain f64 oracle's gradient: where storage rounding ALONE moves a
-    gradient by more than its own norm (0.46 of its norm in round 3, 19 x in round 4 for the same kernels) the relative error of any half-precision
-    run is unbounded, and the distance the emulation itself travels is the scale that means something.  Every other tensor keeps the plain
-    relative error; the streaming compose backward's own gradients are gated without conditioning, op by op, in
+    conditioned (round 6, replaces the bias-only allow-list of rounds 4 / 5): every tensor is classified by how far storage rounding ALONE moves
+    its gradient, travel = |g_emulated - g_plain| / |g_emulated| (g_plain = the plain f64 oracle's gradient of the same network and inputs).
+      * every tensor is first gated against the emulation at grad_median_gate / grad_max_gate (the maximum at <= 2x the largest value measured
+        over all cases): where the forward is bit-faithful the device follows the emulation's rounding decisions and agrees with it far below
+        the distance either keeps from the plain oracle;
+      * a tensor that misses that gate AND has travel > TRAVEL takes the second criterion instead.  Such a tensor's gradient is a near-cancelling sum (the compose net's weights in the small Tiramisu: every one of them moves by
+        63 - 126 % of its norm under storage rounding, its 24 -> 1 biases by 45x) and the emulation is ONE sample of that rounding noise: a second
+        half-precision evaluation with a different fp32 summation order lands anywhere within the same distance.  What can be certified is that
+        the device is AS GOOD an approximation of the true gradient as "round once where the tensor is stored" predicts:
+        |g_device - g_plain| <= 1.15 |g_emulated - g_plain| + 0.02 |g_plain|.  Measured (tools/gate_diag.py, profiles/r06_gate_diag.txt): the device
+        sits at 0.41 - 0.50 of the emulation's distance on every such tensor, fused compose kernels and layer-wise path alike (what VERDICT r5
+        saw drifting, 0.447 -> 0.535 on reused_compose_scales/conv2d_5/kernel, was this noise measured against a gate of the wrong kind).
+    The streaming compose backward's own gradients are gated without any conditioning, op by op, in
     tests/test_gpu_ops.py::test_compose_net_backward_streaming_op_level."""
     from deepdenoiser_amd.architecture import Architecture
     plain = OracleArchitecture(aj, dtype=torch.float64, seed=2)
@@ -80,8 +88,12 @@ def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate
             assert float(got.abs().max()) < 1e-6, p.name
             continue
         e = rel_l2(got, go)
-        if gp is not None and any(p.name.startswith(pre) and p.name.endswith(suf) for pre, suf in CONDITIONED):
-            e = float((got - go).norm() / max(float(go.norm()), float((go - gp).norm())))
+        if (gp is not None and grad_max_gate is not None and e > grad_max_gate
+                and float((go - gp).norm()) > TRAVEL * float(go.norm())):      # rounding-dominated AND off the emulation: gated against the plain oracle
+            d_dev, d_emu, n_plain = float((got - gp).norm()), float((go - gp).norm()), float(gp.norm())
+            gate("%s %s rounding-dominated gradient %s: device-to-plain over (1.15 x emulation-to-plain + 0.02 |g|)" % (what, dtype, p.name),
+                 d_dev / (1.15 * d_emu + 0.02 * n_plain), 1.0)
+            continue
         errs.append((e, p.name))
         if tight is not None and any(p.name.startswith(pre) for pre in tight[0]):
             gate("%s %s gradient %s" % (what, dtype, p.name), e, tight[1])
@@ -117,7 +129,7 @@ def test_cfg2_full_size_half_precision_against_the_storage_emulating_oracle(dtyp
     _compare("cfg-2 128x128 B=2", dtype, aj, tj, 2, 128, 128, *FULL_SIZE_GATES[dtype])
 
 
-SMALL_GATES = {"bf16": (1.5e-2, 1e-3, 0.1, 0.6), "f16": (4e-3, 2e-4, 0.1, 0.6)}
+SMALL_GATES = {"bf16": (1.5e-2, 1e-3, 0.1, 0.22), "f16": (4e-3, 2e-4, 0.1, 0.22)}      # gradient max: measured <= 0.109 over all cases (profiles/r06_*_parity_errors.txt)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -167,7 +179,7 @@ def test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful(case):
     oracle.predict(_inputs(oracle, B, H, W)[0])
     core_convs = [n for n in oracle.vs.vars if n.startswith("reused_core_architecture/conv2d") and "transpose" not in n and n.endswith("/kernel")]
     head = [n[:-len("kernel")] for n in core_convs[-2 * n_scales:]]
-    errs = _compare("bit-faithful " + case, "bf16", aj, tj, B, H, W, 1e-5, 1e-4, 0.1, 0.6, tight=(["reused_compose_scales/"] + head, 1e-4))
+    errs = _compare("bit-faithful " + case, "bf16", aj, tj, B, H, W, 1e-5, 1e-4, 1e-4, 6e-3, tight=(["reused_compose_scales/"] + head, 1e-4))
     assert len(errs) > 10
 
 
