@@ -23,17 +23,8 @@ SYMBOLS = (
     "dd_stitch", "dd_recombine", "dd_probe_tr16", "dd_masked_add", "dd_zero_stuff", "dd_zero_unstuff", "dd_convert_channels",
     "dd_augment", "dd_loss_mask_sums", "dd_crc32c", "dd_extract_tiles", "dd_compose_net_fwd", "dd_compose_net_bwd",
     "dd_kpcn_head_fwd", "dd_kpcn_head_bwd", "dd_kpcn_head_bwd_multi", "dd_assemble_input", "dd_assemble_input_frames", "dd_conv3x3_bwd", "dd_conv3x3_bwd_multi", "dd_convt2x2_fwd", "dd_convt2x2_bwd", "dd_conv3x3_ks",
-    "dd_conv_pw_count", "dd_wgrad_pw_count", "dd_space_to_depth2", "dd_convt3_wgrad", "dd_conv3x3_pair", "dd_compose_stream_plan", "dd_compose_bwd_scratch_bytes",
+    "dd_conv_pw_count", "dd_wgrad_pw_count", "dd_space_to_depth2", "dd_convt3_wgrad", "dd_compose_stream_plan", "dd_compose_bwd_scratch_bytes",
 )
-
-
-class ConvPairArgs(C.Structure):
-    """dd_conv_pair_args (include/dd_hip.h)."""
-    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("cin", C.c_int),
-                ("w1", C.c_void_p), ("n_pad1", C.c_int), ("k_pad1", C.c_int), ("bias1", C.c_void_p), ("cmid", C.c_int), ("flags1", C.c_int),
-                ("w2", C.c_void_p), ("n_pad2", C.c_int), ("k_pad2", C.c_int), ("bias2", C.c_void_p), ("cout", C.c_int), ("flags2", C.c_int),
-                ("y", C.c_void_p), ("ldy", C.c_int),
-                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dtype", C.c_int)]
 
 
 class ConvT3WgradArgs(C.Structure):
@@ -237,7 +228,6 @@ def load():
     lib.dd_conv3x3_ks.argtypes = [C.POINTER(ConvKsArgs), vp]
     lib.dd_space_to_depth2.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp]
     lib.dd_convt3_wgrad.argtypes = [C.POINTER(ConvT3WgradArgs), vp]
-    lib.dd_conv3x3_pair.argtypes = [C.POINTER(ConvPairArgs), vp]
     lib.dd_conv_pw_count.argtypes = []
     lib.dd_conv_pw_count.restype = C.c_long
     lib.dd_wgrad_pw_count.argtypes = []

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["dd_conv_igemm.hip", "dd_conv_wgrad.hip", "dd_pointwise.hip", "dd_compose.hip", "dd_head.hip", "dd_conv_bwd.hip", "dd_convt.hip",
-           "dd_conv_rw.hip", "dd_conv_ks.hip", "dd_conv_pw.hip", "dd_conv_pair.hip", "dd_conv_bwd96.hip", "dd_compose_stream.hip", "dd_compose_stream_bwd.hip"]
+           "dd_conv_rw.hip", "dd_conv_ks.hip", "dd_conv_pw.hip", "dd_conv_bwd96.hip", "dd_compose_stream.hip", "dd_compose_stream_bwd.hip"]
 VERSION_SRC = "dd_version.hip"
 HEADERS = ["dd_common.h", "dd_compose_stream.h", os.path.join("..", "..", "include", "dd_hip.h")]
 LIB = os.path.join(HERE, "libdd_hip.so")
@@ -33,7 +33,6 @@ NO_SCRATCH = {
     "dd_head.hip": ("head_fwd_kernel", "head_bwd_kernel", "head_bwd_multi_kernel"),
     "dd_conv_ks.hip": ("conv_ks_kernel",),
     "dd_conv_pw.hip": ("conv_pw_kernel", "wgrad_pw_kernel"),
-    "dd_conv_pair.hip": ("conv_pair_kernel",),
     "dd_compose_stream.hip": ("compose_stream_fwd_kernel",),
     "dd_compose_stream_bwd.hip": ("compose_stream_wgrad_kernel",),
 }

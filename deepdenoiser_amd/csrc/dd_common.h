@@ -264,7 +264,13 @@ static inline void dd_det_sync() {
   (void)hipGetDevice(&dev);
   if ((armed >> (dev & 63)) & 1ull) return;
   const unsigned init[2] = {1u, 0u};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(dd_det_state), init, sizeof(init));
+  // (synchronous copy: fails during hipGraph capture -- the mode is then NOT armed and the next launch outside a capture tries again; a run
+  //  that asked for DD_DETERMINISTIC=1 must not be reported deterministic on unordered atomics, so the failure is loud.  ADVICE r5)
+  if (hipMemcpyToSymbol(HIP_SYMBOL(dd_det_state), init, sizeof(init)) != hipSuccess) {
+    (void)hipGetLastError();
+    fprintf(stderr, "libdd_hip: DD_DETERMINISTIC=1 could not be armed on device %d (first launch of a translation unit inside a graph capture?): run one eager step first\n", dev);
+    return;
+  }
   armed |= 1ull << (dev & 63);
 }
 

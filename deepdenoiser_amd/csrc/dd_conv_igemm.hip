@@ -843,12 +843,7 @@ static bool ws_enabled() {
   return v != 0;
 }
 
-static size_t lds_budget() {   // LDS a workgroup may use when deciding weight residency (DD_CONV_RESIDENT_BUDGET_KB=79 => 2 workgroups/CU)
-  static size_t v = 0;
-  if (!v) { const char* e = getenv("DD_CONV_RESIDENT_BUDGET_KB"); v = (size_t)(e ? atoi(e) : 158) * 1024; }
-  return v;
-}
-#define LDS_BUDGET lds_budget()
+#define LDS_BUDGET ((size_t)158 * 1024)      // LDS a workgroup may use when deciding weight residency (one workgroup per CU)
 
 template <typename T, int NT>
 int launch_nt(const ConvP& p, hipStream_t stream) {
@@ -865,18 +860,8 @@ int launch_nt(const ConvP& p, hipStream_t stream) {
   return resident ? launch<T, NT, false, true>(p, nslabs, stream) : launch<T, NT, false, false>(p, nslabs, stream);
 }
 
-// Channel-block width policy.  DD_CONV_POLICY=wide keeps the widest block (fewest patch re-reads, best MFMA:LDS ratio);
-// the default prefers a block narrow enough for its weights to stay resident in LDS, but never narrower than min_resident_nt.
-static int conv_policy_min_resident_nt() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DD_CONV_MIN_RESIDENT_NT");
-    v = e ? atoi(e) : 2;
-    const char* w = getenv("DD_CONV_POLICY");
-    if (w && strcmp(w, "wide") == 0) v = 1000;
-  }
-  return v;
-}
+// Channel-block width policy: a block narrow enough for its weights to stay resident in LDS, but never narrower than two 16-channel tiles.
+static int conv_policy_min_resident_nt() { return 2; }
 
 template <typename T>
 int dispatch(ConvP& p, hipStream_t stream) {

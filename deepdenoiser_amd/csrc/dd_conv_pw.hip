@@ -312,26 +312,14 @@ bool pw_enabled() {
   if (v < 0) { const char* e = getenv("DD_CONV_PW"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
 }
-int pw_min_k() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DD_CONV_PW_MIN_K"); v = e ? atoi(e) : 0; }
-  return v;
-}
-int pw_gather9() {      // DD_CONV_PW_GATHER=0: wide gather-form data gradients stay on the K-streamed kernel
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DD_CONV_PW_GATHER"); v = e ? atoi(e) : 1; }
-  return v;
-}
+int pw_min_k() { return 0; }
+int pw_gather9() { return 1; }      // wide gather-form data gradients take the nine-tap GEMM form
 int pwg_mid() {      // DD_WGRAD_PW_MID=1: also take the mid-sized gradients (129 ... 256 channels on the wider side)
   static int v = -1;
   if (v < 0) { const char* e = getenv("DD_WGRAD_PW_MID"); v = e ? atoi(e) : 0; }
   return v;
 }
-long pw_min_pixels() {
-  static long v = -1;
-  if (v < 0) { const char* e = getenv("DD_CONV_PW_MIN_PIXELS"); v = e ? atol(e) : 32768; }
-  return v;
-}
+long pw_min_pixels() { return 32768; }
 
 template <typename T, int CTN>
 void pw_launch_ctn(const PwP& p, bool in_relu, unsigned grid, hipStream_t s) {
@@ -695,7 +683,6 @@ static int pwg_plan_and_launch(PwgP& p, int dtype, hipStream_t s) {
   p.mblk = (nmt + mt - 1) / mt; p.nblk = (nnt + nt - 1) / nt;
   const int ntp = p.mblk * p.nblk;
   int spx = pw_cus() / 8 / ntp;
-  { static int force = -1; if (force < 0) { const char* e = getenv("DD_PWG_SPX"); force = e ? atoi(e) : 0; } if (force > 0) spx = force; }
   if (spx < 1) spx = 1;
   while (spx > 1 && (long)spx * 8 > p.nunits) --spx;
   p.spx = spx;

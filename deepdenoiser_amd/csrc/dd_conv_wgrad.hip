@@ -793,8 +793,7 @@ extern "C" int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream) {
   const long total_tiles = (long)a->B * p.tiles_x * p.tiles_y;
   int ksplit = a->ksplit;
   if (ksplit <= 0) {
-    static int target = 0;
-    if (!target) { const char* e = getenv("DD_WGRAD_BLOCKS"); target = e ? atoi(e) : 256; }   // measured: 256 workgroups (1/CU) beat 128 / 512 / 1024 (atomics vs overlap)
+    const int target = 256;   // measured: 256 workgroups (1/CU) beat 128 / 512 / 1024 (atomics vs overlap)
     ksplit = (int)(target / ((long)p.mslices * p.nslices));
     if (ksplit < 1) ksplit = 1;
   }

@@ -804,9 +804,7 @@ extern "C" int dd_kpcn_head_bwd_multi(const dd_head_args* a, int n, dd_stream st
     p.N = b->N; p.H = b->H; p.W = b->W; p.npix = (long)b->N * b->H * b->W;
     m.nch[i] = (b->C + 31) / 32;
     // measured cycles per 32-pixel step of a wave (tools/head_phases.py, 5 x 5): 32 / 64 / 96 / 128 channels
-    static double step_cost[5] = {0.0, 12.0, 17.0, 16.0, 23.0};
-    static const bool tuned = [] { const char* e = getenv("DD_HEAD_MULTI_W"); if (e) sscanf(e, "%lf,%lf,%lf,%lf", &step_cost[1], &step_cost[2], &step_cost[3], &step_cost[4]); return true; }();
-    (void)tuned;
+    static const double step_cost[5] = {0.0, 12.0, 17.0, 16.0, 23.0};
     work[i] = (double)((p.npix + 31) / 32) * step_cost[m.nch[i]] + 2.0 * BWD_WAVES * step_cost[m.nch[i]];      // (+ a fixed share: nobody gets zero workgroups)
     total += work[i];
     const size_t l = head_bwd_lds(b->ksize, m.nch[i]);

@@ -161,7 +161,7 @@ extern "C" int dd_colsum(const void* x, int ld, int c, long rows, float* out, in
     int nv = 1;
     while (nv * per16 < c) nv *= 2;
     static const bool vec_on = [] { const char* e = getenv("DD_COLSUM_VEC"); return !(e && e[0] == '0'); }();
-    if (vec_on && dd_dtype_ok(dtype) && nv <= 8 && nv * per16 <= ld && ld % per16 == 0 && ((uintptr_t)x % 16) == 0 && (ld * esz) % 16 == 0) {
+    if (vec_on && dd_dtype_ok(dtype) && nv <= 8 && (c + per16 - 1) / per16 * per16 <= ld && ld % per16 == 0 && ((uintptr_t)x % 16) == 0 && (ld * esz) % 16 == 0) {
       const int row0 = 0;
       return dd_colsum_segments(x, ld, c, rows, 1, out, c, &row0, dtype, stream);
     }
@@ -210,7 +210,10 @@ __global__ __launch_bounds__(256) void colsum_segments_kernel(const ColsumSegP p
 #pragma unroll
   for (int e = 0; e < N; ++e) s[e] = 0.f;
   const long rstep = (long)gridDim.x * (256 / nv);
-  for (long r = (long)blockIdx.x * (256 / nv) + threadIdx.x / nv; r < p.rows; r += rstep) {
+  // (nv is a power of two; vectors past the channel count -- 24 channels are 3 vectors of 4 -- are not loaded: the caller may hand over a
+  //  channel VIEW whose row ends with its last real vector, and the last row's surplus vector would lie outside the allocation: ADVICE r5)
+  const bool live = v * N < p.c;
+  for (long r = (long)blockIdx.x * (256 / nv) + threadIdx.x / nv; live && r < p.rows; r += rstep) {
     float t[N];
     vload<T>(base + r * p.ld, t);
 #pragma unroll
@@ -236,7 +239,7 @@ extern "C" int dd_colsum_segments(const void* x, int ld, int c, long rows_per_se
   const int per16 = dtype == DD_F32 ? 4 : 8, esz = dtype == DD_F32 ? 4 : 2;
   int nv = 1;
   while (nv * per16 < c) nv *= 2;
-  DD_REQUIRE(nv <= 8 && nv * per16 <= ld && ld % per16 == 0 && ((uintptr_t)x % 16) == 0 && (ld * esz) % 16 == 0,
+  DD_REQUIRE(nv <= 8 && (c + per16 - 1) / per16 * per16 <= ld && ld % per16 == 0 && ((uintptr_t)x % 16) == 0 && (ld * esz) % 16 == 0,
              "dd_colsum_segments: c=%d ld=%d (at most %d channels, rows of whole 16-byte vectors that cover them)", c, ld, 8 * per16);
   ColsumSegP p;
   p.x = x; p.out = out; p.rows = rows_per_segment; p.ld = ld; p.c = c; p.nv = nv; p.out_ld = out_ld;
@@ -1746,7 +1749,7 @@ extern "C" int dd_loss_head(const dd_loss_desc* desc, int B, int H, int W, float
     P.kind = desc->kind; P.eps = desc->epsilon; P.grad_scale = grad_scale; P.nvec = npix * 3 / 4; P.loss_out = loss_out;
     dd_det_sync();
     const long want = (P.nvec + 511) / 512;
-    static const long cap = [] { const char* e = getenv("DD_LOSS_BLOCKS"); return e ? atol(e) : 1024L; }();      // (one atomic per workgroup into ONE address: 2 048 of them measured 8 us slower than 1 024 over the three scales)
+    const long cap = 1024L;      // (one atomic per workgroup into ONE address: 2 048 of them measured 8 us slower than 1 024 over the three scales)
     hipLaunchKernelGGL(loss_simple_kernel, dim3((unsigned)(want < cap ? (want < 1 ? 1 : want) : cap)), dim3(256), 0, S(stream), P);
     DD_LAUNCH_CHECK();
     return DD_OK;

@@ -303,7 +303,6 @@ class Graph:
         grid the flush this saves is a few per cent of the launch and the launches stay apart (DD_WGRAD_MULTI=0: always)."""
         if os.environ.get("DD_WGRAD_MULTI", "1") == "0":
             return
-        max_pixels = int(os.environ.get("DD_WGRAD_MULTI_PIXELS", max_pixels))
         ops, lib = self.bwd_ops, self.lib
         by_grid = {}
         for i, op in enumerate(ops):
@@ -536,12 +535,10 @@ class Graph:
             gy = y.grad()
             self._self_mask(y, gy)
             # one pass over dy and x for both gradients (3x3, <= 64 output channels, bf16 / f16 storage): csrc/dd_conv_bwd.hip
-            # (more than 64 output channels: dd_conv3x3_bwd runs one launch per 64 of them, each re-reading x and re-writing dx -- measured
-            #  slower than the register-weight data gradient + the weight-gradient role: 4.80 against 4.10 ms per step; opt-in only)
+            # (more than 96 output channels with a data gradient: the register-weight data gradient + the weight-gradient role as two launches)
             # (round 6: 65 - 96 output channels with a data gradient have a fused kernel of their own, csrc/dd_conv_bwd96.hip: a 32-channel third
             #  of the input per workgroup against all output channels; DD_CONV_BWD96=0 restores the two-launch path)
-            wide_ok = (layer.cout <= 64 or (x.requires_grad and layer.cout <= 96 and os.environ.get("DD_CONV_BWD96", "1") != "0")
-                       or (x.requires_grad and os.environ.get("DD_FUSE_CONV_BWD_WIDE", "0") != "0"))
+            wide_ok = layer.cout <= 64 or (x.requires_grad and layer.cout <= 96 and os.environ.get("DD_CONV_BWD96", "1") != "0")
             wide_ok = wide_ok and x.B * x.H * x.W < (1 << 23)      # dd_conv3x3_bwd's own limit (linear pixel index in the DMA swizzle): larger problems split
             if (layer.k == 3 and self.dtype in ("bf16", "f16") and wide_ok and not in_relu and (x.requires_grad or layer.cin >= 16)
                     and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):
@@ -560,7 +557,7 @@ class Graph:
                 return
             wflags = L.IN_RELU if in_relu else 0
             if (layer.k == 3 and self.dtype in ("bf16", "f16") and layer.cout > 64 and not in_relu and layer.cin >= 16 and x.B * x.H * x.W < (1 << 23)
-                    and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0" and os.environ.get("DD_WGRAD_VIA_BWD", "1") != "0"):
+                    and os.environ.get("DD_FUSE_CONV_BWD", "1") != "0"):
                 # > 64 output channels: the weight-gradient role of the fused backward kernel per (input block, output block) pair of 64 x 64
                 # channels (dx = NULL).  Measured faster than the dedicated weight-gradient kernel: 96->96 at 64x64 154 -> 115 us,
                 # 128->128 at 32x32 71 -> 60 us against csrc/dd_conv_wgrad.hip
@@ -699,43 +696,6 @@ class Graph:
                                       mask.ld if mask is not None else 0, dst_tensor.Cp, dst_tensor.npix, acc, code, stream))
         self.bwd(run)
         dst_tensor.mark_grad_written()
-
-    def conv_pair(self, x, layer1, layer2, relu1=True, relu2=True, out=None):
-        """Two consecutive tf.layers.conv2d(3x3, SAME) [+ ReLU] of the 64-channel level as ONE launch (csrc/dd_conv_pair.hip): forward only -- the
-        tensor between them exists in LDS only, so there is nothing to differentiate through.  The caller checks pair_eligible()."""
-        assert self.pair_eligible(x, layer1, layer2) and not bool(getattr(self, "training", True))
-        y = out if out is not None else self.tensor(x.B, x.H, x.W, layer2.cout, relu=relu2)
-        y.relu = relu2
-        ps, lib = self.params, self.lib
-        w1, _, n_pad1, k_pad1 = layer1.packed("fwd")
-        w2, _, n_pad2, k_pad2 = layer2.packed("fwd")
-        for lay in (layer1, layer2):
-            rec = {"flops": 2.0 * x.B * x.H * x.W * 9 * lay.cin * lay.cout, "B": x.B, "H": x.H, "W": x.W, "taps": 9, "n": lay.cout, "k": lay.cin,
-                   "extra_reads": 0, "flags": L.OUT_RELU}
-            self.conv_records.append(rec)
-
-        def conv_pair(stream, cell=[]):
-            if not cell:
-                a = L.ConvPairArgs()
-                a.x, a.ldx, a.cin = x.ptr, x.ld, x.Cp
-                a.w1, a.n_pad1, a.k_pad1, a.bias1, a.cmid, a.flags1 = w1.data_ptr(), n_pad1, k_pad1, ps.value_ptr(layer1.bias), layer1.cout, (L.OUT_RELU if relu1 else 0)
-                a.w2, a.n_pad2, a.k_pad2, a.bias2, a.cout, a.flags2 = w2.data_ptr(), n_pad2, k_pad2, ps.value_ptr(layer2.bias), round_up(layer2.cout, 4), (L.OUT_RELU if relu2 else 0)
-                a.y, a.ldy = y.ptr, y.ld
-                a.B, a.H, a.W, a.dtype = x.B, x.H, x.W, self.code
-                cell.append(a)
-            L.check(lib.dd_conv3x3_pair(C.byref(cell[0]), stream))
-        conv_pair.tag, conv_pair.info = "conv_igemm", {"flops": 2.0 * x.B * x.H * x.W * 9 * (layer1.cin * layer1.cout + layer2.cin * layer2.cout), "B": x.B, "H": x.H,
-                                                       "W": x.W, "taps": 9, "n": layer2.cout, "k": layer1.cin + layer2.cin, "flags": L.OUT_RELU}
-        self.fwd(conv_pair)
-        return y
-
-    def pair_eligible(self, x, layer1, layer2):
-        return (self.dtype in ("bf16", "f16") and layer1.kind == "conv" and layer2.kind == "conv" and layer1.k == 3 and layer2.k == 3
-                and x.C == layer1.cin and x.Cp <= 64 and 48 < layer1.cout <= 64 and layer1.cout % 16 == 0 and layer2.cin == layer1.cout and layer2.cout <= 64
-                and layer2.cout % 4 == 0 and x.ld % 8 == 0 and x.ch0 % 8 == 0 and os.environ.get("DD_CONV_PAIR", "0") != "0")
-        # (Off by default since round 4: with the next tile's DMA issued early the single 64 -> 64 launches take 195 us on the 209 tiles of a frame,
-        #  two of them 390 us against the pair kernel's 498 us -- same box, DD_CONV_PAIR=1 -> 0: 407.5 -> 421.1 MPix/s.  The kernel stays tested
-        #  through Graph.conv_pair and reachable with DD_CONV_PAIR=1.)
 
     def conv_transpose2(self, x, layer, out=None, relu=True):
         """tf.layers.conv2d_transpose(2x2, strides 2) + ReLU (UNet.py:54-59)."""
@@ -905,7 +865,7 @@ class Graph:
         y = out if out is not None else self.tensor(x.B, OH, OW, x.C, requires_grad=x.requires_grad)
         assert (y.H, y.W, y.C) == (OH, OW, x.C)
         # the argmax plane only feeds the backward: inference graphs do not store it
-        idx = torch.zeros((x.B, OH, OW, x.Cp), dtype=torch.uint8, device=self.device) if (bool(getattr(self, "training", True)) or os.environ.get("DD_MAXPOOL_KEEP_IDX", "0") == "1") else None
+        idx = torch.zeros((x.B, OH, OW, x.Cp), dtype=torch.uint8, device=self.device) if bool(getattr(self, "training", True)) else None
         lib, code = self.lib, self.code
 
         def run(stream):

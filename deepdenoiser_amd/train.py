@@ -69,6 +69,7 @@ class TileStream:
         self.arch, self.batch, self.tile, self.spp, self.tuples = arch, batch, tile, spp, index_tuples
         self.rank, self.world, self.rng, self.prefetch, self.pinned = rank, world, rng, prefetch, pinned
         self.pad_last, self.padded, self.dropped, self._const = pad_last, 0, 0, {}
+        self.real_in_last = batch          # real (not repeated) examples in this rank's LAST mini-batch of the epoch (pad_last)
         self.passes = {f.name: f.number_of_channels for f in arch.feature_predictions + arch.auxiliary_features if f.load_data}
         self.targets = [f.name for f in arch.feature_predictions if f.load_data and f.is_target]
         self.required = sorted({i for t in index_tuples for i in t})
@@ -185,8 +186,13 @@ class TileStream:
                     feed(ex)
                 left = len(group) * self.batch + len(buf)
                 if left and self.pad_last and head:
-                    for k in range(need - left):                         # fill the last round with examples from the start of the epoch
-                        feed(head[k % len(head)])
+                    # fill the last round by cycling over ITS OWN examples (not the start of the epoch: those would be counted twice), and
+                    # tell the consumer how many of this rank's last mini-batch are real: it weighs that mini-batch's mean by the count, a
+                    # mini-batch of repeats only by zero (the fixed-size programme cannot evaluate a smaller remainder batch)
+                    tail = [ex for b in group for ex in b] + list(buf)
+                    self.real_in_last = max(0, min(self.batch, left - self.rank * self.batch))
+                    for k in range(need - left):
+                        feed(tail[k % len(tail)])
                     self.padded = need - left
                 else:
                     self.dropped = left
@@ -237,12 +243,17 @@ def run_validation(trainer, arch, tj, base, B, rank, world, threads):
             continue
         stream = TileStream(vdir, "validation", arch, B, st["tiles_height_width"], spp, tuples, rank, world, rng=None, threads=threads, pad_last=True)
         total = torch.zeros(2, dtype=torch.float64, device=arch.device)
+        losses = []
         for feats, labels in stream:
             trainer.program.set_inputs({k: v.to(arch.device) for k, v in feats.items()}, {k: v.to(arch.device) for k, v in labels.items()})
             trainer.program.zero_grads()
             trainer.program.forward()
-            total[0] += trainer.program.loss_buf.double().sum()
-            total[1] += 1
+            losses.append(trainer.program.loss_buf.double().sum())
+        # every example counts once: a mini-batch's mean is weighed by its REAL examples (the last round of the epoch is filled with repeats)
+        for i, l in enumerate(losses):
+            w = stream.real_in_last if (stream.padded and i == len(losses) - 1) else B
+            total[0] += l * w
+            total[1] += w
         if world > 1:
             dist.all_reduce(total)
         if float(total[1]) > 0:

@@ -108,20 +108,6 @@ typedef struct {
 } dd_wgrad_args;
 int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream);
 
-/* ---- two consecutive 3x3 SAME convs (bias + optional ReLU each) as ONE launch, forward only: the inference forward of a U-Net block (UNet.py:25-48:
- * `number_of_convolutions_per_block` tf.layers.conv2d in a row; Prediction.py:357-369 never differentiates them).  bf16 / f16 storage, at most 64
- * channels everywhere (the 64-channel level), 49..64 in between; the tensor between the two layers lives in LDS only.
- *   y = act2(b2 + w2 (*) act1(b1 + w1 (*) x)),  both convolutions zero-padded at the image border as TensorFlow pads each layer.
- * w1 / w2: dd_pack_weights images of the two layers as dd_conv_igemm takes them, [9][64][k_pad1 = 32 | 64] and [9][n_pad2 <= 64][64]. */
-typedef struct {
-  const void* x; int ldx; int cin;                                                  /* [B,H,W,ldx], cin % 8 == 0, cin <= 64 */
-  const void* w1; int n_pad1; int k_pad1; const float* bias1; int cmid; int flags1;   /* flags: DD_OUT_RELU or 0 */
-  const void* w2; int n_pad2; int k_pad2; const float* bias2; int cout; int flags2;
-  void* y; int ldy;                                                                 /* [B,H,W,ldy] */
-  int B, H, W; int dtype;
-} dd_conv_pair_args;
-int dd_conv3x3_pair(const dd_conv_pair_args* a, dd_stream stream);
-
 /* ---- fused backward of a 3x3 SAME conv2d (stride 1): the data gradient (Conv2DBackpropInput + the ReluGrad of the layer's input) AND the
  * weight / bias gradients (Conv2DBackpropFilter, BiasAddGrad) that TensorFlow's autodiff emits for tf.layers.conv2d (Training.py:701-702 over
  * UNet.py:38-48), from ONE pass over dy and x (dd_conv_igemm + dd_conv_wgrad fetch each of them twice).  bf16 / f16 storage, cout <= 64.
@@ -380,8 +366,9 @@ typedef struct {
   const float* mask_sums;                /* device, [DD_MAX_FEATURES + DD_MAX_COMBINED]: sum of each source's mask over the batch (dd_loss_mask_sums);
                                             may be NULL when no masked weight is set */
   /* Optional fusion of FeaturePrediction.prediction_invert_standardization (Architecture.py:134-138, :47-55; Utilities.py:3-7) into the loss
-   * launch, per feature; only for features-only descriptors (n_combined = 0, no image / variation / masked terms, pred_ld = target_ld = 3,
-   * 16-byte aligned blocks) -- anything else is rejected.  With pred_std[f] != NULL the launch reads the STANDARDIZED prediction x from
+   * launch, per feature; for every descriptor WITHOUT variation terms (features-only ones take the flat-stream kernel, descriptors with
+   * combined / image / masked terms the per-pixel kernel; with a variation term dd_loss_head rejects pred_std: run dd_invert_std_fwd / _bwd
+   * around it).  With pred_std[f] != NULL the launch reads the STANDARDIZED prediction x from
    * pred_std[f], stores p = sign(z) expm1|z| (inv_log1p) or z, z = x inv_std + inv_mean, to pred_inv[f] (what dd_invert_std_fwd stores),
    * and writes dL/dx (what dd_invert_std_bwd stores) to dpred[f] instead of dL/dp; pred[f] is not read. */
   const float* pred_std[DD_MAX_FEATURES];

@@ -59,7 +59,7 @@ def test_struct_sizes_match_header(lib):
     src = r'''
 #include <stdio.h>
 #include "dd_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dd_conv_pair_args), sizeof(dd_convt3_wgrad_args), sizeof(dd_conv_ks_args), sizeof(dd_convt_args), sizeof(dd_conv_bwd_args), sizeof(dd_assemble_entry), sizeof(dd_head_args), sizeof(dd_compose_bwd_args), sizeof(dd_compose_args), sizeof(dd_conv_args), sizeof(dd_wgrad_args), sizeof(dd_feature_params),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dd_convt3_wgrad_args), sizeof(dd_conv_ks_args), sizeof(dd_convt_args), sizeof(dd_conv_bwd_args), sizeof(dd_assemble_entry), sizeof(dd_head_args), sizeof(dd_compose_bwd_args), sizeof(dd_compose_args), sizeof(dd_conv_args), sizeof(dd_wgrad_args), sizeof(dd_feature_params),
   sizeof(dd_gather_entry), sizeof(dd_loss_desc), sizeof(dd_stitch_entry), sizeof(dd_recombine_desc), sizeof(dd_pack_desc), sizeof(dd_augment_draw)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -68,7 +68,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu 
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    mirror = [ctypes.sizeof(t) for t in (_lib.ConvPairArgs, _lib.ConvT3WgradArgs, _lib.ConvKsArgs, _lib.ConvTArgs, _lib.ConvBwdArgs, _lib.AssembleEntry, _lib.HeadArgs, _lib.ComposeBwdArgs, _lib.ComposeArgs, _lib.ConvArgs, _lib.WgradArgs, _lib.FeatureParams, _lib.GatherEntry, _lib.LossDesc, _lib.StitchEntry, _lib.RecombineDesc, _lib.PackDesc, _lib.AugmentDraw)]
+    mirror = [ctypes.sizeof(t) for t in (_lib.ConvT3WgradArgs, _lib.ConvKsArgs, _lib.ConvTArgs, _lib.ConvBwdArgs, _lib.AssembleEntry, _lib.HeadArgs, _lib.ComposeBwdArgs, _lib.ComposeArgs, _lib.ConvArgs, _lib.WgradArgs, _lib.FeatureParams, _lib.GatherEntry, _lib.LossDesc, _lib.StitchEntry, _lib.RecombineDesc, _lib.PackDesc, _lib.AugmentDraw)]
     assert sizes == mirror
 
 

@@ -32,6 +32,14 @@ CASES = {   # name: (environment of the child, -k expression[, test file (defaul
     # backward per scale, the per-channel-lane column sums, thin layers K-streamed
     "round5_merges_off": ({"DD_WGRAD_STACK": "0", "DD_WGRAD_MULTI": "0", "DD_HEAD_BWD_MULTI": "0", "DD_COLSUM_VEC": "0", "DD_CONV_KS_THIN": "1"},
                           "test_small_networks_half_precision or test_backward_of_the_fused or test_cfg2_full_size_half", "test_gpu_round3.py"),
+    # round 6: the fused backward of the 65 - 96-channel level (csrc/dd_conv_bwd96.hip) off -> the two launches it replaced: the 12-wave masked
+    # register-weight data gradient + the weight-gradient role per 64 x 64 block pair; and the engine-level paths of rounds 1 / 2 that no
+    # default configuration reaches any more (unfused input assembly, layer-wise transposed conv, one-launch conv over the skip concat, the
+    # two-launch backward of every 3 x 3 layer), on the half-precision networks that would otherwise never run them
+    "two_launch_backward_of_the_96_channel_level": ({"DD_CONV_BWD96": "0"},
+                                                    "test_conv3x3_random_shapes_round2_kernels or test_conv_grad_accumulation or test_conv_over_skip_concat"),
+    "engine_paths_of_rounds_1_and_2": ({"DD_FUSE_INPUT": "0", "DD_CONVT_STREAM": "0", "DD_CONV_SPLIT_CONCAT": "0", "DD_FUSE_CONV_BWD": "0"},
+                                       "test_small_networks_half_precision and (cfg2 or example_json or ragged)", "test_gpu_round3.py"),
     "tile_compose_kernels_bit_faithful": ({"DD_COMPOSE_STREAM": "0", "DD_COMPOSE_STREAM_BWD": "0"},
                                           "test_backward_of_the_fused_head_and_compose_kernels_is_bit_faithful", "test_gpu_round3.py"),
 }

@@ -669,15 +669,6 @@ def test_conv3x3_random_shapes_round2_kernels(eng, seed):
         _conv_case(eng, dtype, 3, cin, cout, H, W, relu, False, residual, x_relu, B=B, x_requires_grad=rng.random() < 0.85)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("cin,cout,H,W", [(96, 96, 20, 28), (128, 128, 16, 16), (64, 80, 9, 33)])
-def test_conv_fused_backward_wide_layers_opt_in(eng, dtype, cin, cout, H, W, monkeypatch):
-    """dd_conv3x3_bwd with more than 64 output channels AND a data gradient: one launch per 64 output channels, the later ones accumulating
-    into dx (opt-in, DD_FUSE_CONV_BWD_WIDE=1: measured slower than the split path, kept correct)."""
-    monkeypatch.setenv("DD_FUSE_CONV_BWD_WIDE", "1")
-    _conv_case(eng, dtype, 3, cin, cout, H, W, True, False, False, True, B=2, expect_fused_bwd=True)
-
-
 # The GEMM-tile kernels on channel VIEWS of concat buffers, which is how the Tiramisu lowering calls them (row pitch wider than the channel count,
 # non-zero channel offsets, neighbours that must not be touched): the 1x1 transition conv reads buf[:, c0:c0+C] and its data gradient is masked by
 # and accumulated into the same range of the gradient buffer; the transposed conv reads such a view and writes the next level's range.
@@ -742,41 +733,6 @@ def test_gemm_tile_kernels_on_concat_views(lib, eng, dtype, kind, C, cout, c0, l
     hi, lo = max(C, cout), min(C, cout)
     pw_wgrad = kind == "1x1" and not (128 < hi <= 256 and lo > 32)      # the mid-sized weight gradient stays on the 64 x 64-slice kernel
     assert lib.dd_conv_pw_count() - before >= 1 and lib.dd_wgrad_pw_count() - wbefore == int(pw_wgrad)
-
-
-# Two 3x3 convs + ReLU of the 64-channel level as one launch (csrc/dd_conv_pair.hip): inference graphs only.  Ragged 16 x 14 tiles, images smaller
-# than a tile, fewer input / output channels than 64, the zero padding of the INTERMEDIATE at the image border.
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("cin,cmid,cout,H,W,B,relu2", [(64, 64, 64, 128, 128, 2, True), (32, 64, 64, 33, 45, 1, True), (64, 64, 48, 16, 16, 3, False),
-                                                         (24, 64, 64, 20, 28, 2, True), (64, 64, 64, 5, 9, 2, True), (64, 64, 64, 256, 270, 1, True)])
-def test_conv_pair_inference_forward(eng, dtype, cin, cmid, cout, H, W, B, relu2, monkeypatch):
-    monkeypatch.setenv("DD_CONV_PAIR", "1")      # (off by default since round 4: two single launches are faster; the kernel stays tested)
-    gen = _gen(cin * 5 + cout + H)
-    g = eng.Graph("cuda", dtype)
-    g.training = False
-    x = g.tensor(B, H, W, cin, relu=False, requires_grad=False)
-    l1, l2 = g.layer("p/conv2d", 3, cin, cmid), g.layer("p/conv2d_1", 3, cmid, cout)
-    assert g.pair_eligible(x, l1, l2)
-    wide = g.tensor(B, H, W, cout + 24, requires_grad=False)
-    y = g.conv_pair(x, l1, l2, relu1=True, relu2=relu2, out=wide.view(8, cout))
-    g.finalize()
-    assert [op.__name__ for op in g.fwd_ops] == ["conv_pair"]
-    xv = representable(torch.randn(B, H, W, cin, generator=gen, dtype=torch.float64), dtype)
-    w1 = representable(torch.randn(3, 3, cin, cmid, generator=gen, dtype=torch.float64) / (3 * cin ** 0.5), dtype)
-    w2 = representable(torch.randn(3, 3, cmid, cout, generator=gen, dtype=torch.float64) / (3 * cmid ** 0.5), dtype)
-    b1 = torch.randn(cmid, generator=gen, dtype=torch.float64).float().double()
-    b2 = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
-    set_param(g.params, l1.kernel, w1); set_param(g.params, l1.bias, b1)
-    set_param(g.params, l2.kernel, w2); set_param(g.params, l2.bias, b2)
-    fill(x, xv)
-    wide.buf.fill_(3.0)
-    g.run(g.pack_ops); g.run(g.fwd_ops)
-    torch.cuda.synchronize()
-    mid = representable(T.conv2d_same(xv, w1, b1, True), dtype)      # the intermediate is rounded to the storage type, as the two-launch path stores it
-    want = T.conv2d_same(mid, w2, b2, relu2)
-    check("y", read(y), want, 2 * ROUND[dtype])      # (a stored intermediate value on the other side of a rounding boundary moves an output by one more rounding)
-    untouched = float((wide.buf[..., :8].float() - 3.0).abs().max()) == 0.0 and float((wide.buf[..., 8 + cout:].float() - 3.0).abs().max()) == 0.0
-    assert untouched, "channels next to the output range were written"
 
 
 # ---------------------------------------------------------------------------------------------------------------- compose net backward, op level

@@ -75,7 +75,7 @@ def test_evaluation_jsons_lists_the_validation_sets(tmp_path):
 
 def test_validation_stream_pads_its_last_round_and_training_counts_what_it_drops(tmp_path):
     """35 examples, batch 4, two ranks: training drops the 3 left after 4 rounds and says so; a validation stream (pad_last) fills a fifth round
-    with repeats from the start of the epoch, so every example is evaluated."""
+    with repeats of its own three examples, and weighs the last mini-batch by its real examples, so every example counts exactly once."""
     aj = configs.architecture(filters=(16, 24), convs=1, flag_mode="NONE")
     arch = Architecture(aj, device="cpu")
     base = str(tmp_path / "data")
@@ -83,13 +83,18 @@ def test_validation_stream_pads_its_last_round_and_training_counts_what_it_drops
     B, world = 4, 2
     tr = TileStream(os.path.join(base, "training"), "training", arch, B, T, SPP, [[0]], 0, world, rng=None, threads=2, pinned=False)
     assert len(_ids(tr, first)) == 4 and tr.dropped == 3 and tr.padded == 0
-    seen = []
+    seen, real, last_round = [], [], []
     for rank in range(world):
         va = TileStream(os.path.join(base, "training"), "training", arch, B, T, SPP, [[0]], rank, world, rng=None, threads=3, pinned=False, pad_last=True)
         ids = _ids(va, first)
         assert len(ids) == 5 and va.padded == 5 and va.dropped == 0
         seen += [i for b in ids for i in b]
+        # (round 6) the weights run_validation gives the mini-batches: B for whole rounds, the REAL examples of the last one
+        real += [i for b in ids[:-1] for i in b] + ids[-1][:va.real_in_last]
+        last_round += ids[-1]
     assert set(seen) == set(range(n)) and len(seen) == 40
+    assert sorted(real) == list(range(n)), "every example must carry weight exactly once"
+    assert set(last_round) == set(range(32, 35)), "the last round repeats its own examples, not the start of the epoch"
     # a set smaller than one round still yields one (it yielded nothing before)
     small = str(tmp_path / "small")
     first, n = _dataset(small, arch, n_files=1, per_file=3)
