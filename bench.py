@@ -44,7 +44,7 @@ def synthetic_inputs(arch, B, H, W, device, seed):
     return feats, labels
 
 
-def measured_traffic(B, dtype):
+def measured_traffic(B, dtype, family="conv_igemm"):
     """HBM bytes per conv_igemm launch from the committed PMC measurement of this configuration (profiles/*_hbm_traffic.json: FETCH_SIZE /
     WRITE_SIZE passes of rocprofv3, collected and corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be collected from inside the
     timed run, so the figure is reported only when a measurement of the same batch size and dtype exists; otherwise null."""
@@ -53,6 +53,11 @@ def measured_traffic(B, dtype):
         try:
             m = json.load(open(path))
         except (OSError, ValueError):
+            continue
+        if family == "conv_bwd":      # conv_bwd_kernel + conv_bwd96_kernel (the PMC table lists them under one substring)
+            if m.get("tiles_per_gpu_per_step") == B and m.get("dtype") == dtype and "conv_bwd" in m:
+                c = m["conv_bwd"]
+                return {"bytes_per_launch": 1e6 * (c["fetch_MB_per_launch"] + c["write_MB_per_launch"]), "source": os.path.relpath(path, ROOT)}
             continue
         if m.get("tiles_per_gpu_per_step") == B and m.get("dtype") == dtype and ("conv_igemm" in m or "conv_rw" in m):      # (round 4: every launch of the family is a register-weight kernel)
             # the bench's conv_igemm launch family = the LDS-weight kernels plus the register-weight kernel dd_conv_igemm forwards to (PMC lists
@@ -85,6 +90,9 @@ def family_bytes(launches, family, esz):
     """Algorithmic HBM bytes of the TIMED launches of one family (the per-launch records profile_ops returns -- the same list the family's time
     and flops come from): every input and output element once, plus the output-shaped operands a launch reads (ReLU mask, residual, the
     gradient it accumulates into)."""
+    if family == "conv_bwd":      # fused backward: dy (k = C_out) + x (n = C_in) read, dx (n) written unless weights-only, + the gradient it accumulates into
+        return sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + (0 if r.get("weights_only") else 1) + (1 if r.get("accumulate") else 0))) * esz
+                   for tag, r, _ in launches if tag == family and r and "k" in r and "n" in r)
     return sum(r["B"] * r["H"] * r["W"] * (r["k"] + r["n"] * (1 + r.get("extra_reads", 0))) * esz
                for tag, r, _ in launches if tag == family and r and "k" in r and "n" in r)
 
@@ -288,7 +296,8 @@ def extras(device, B, H, W):
         torch.cuda.empty_cache()
     # ---- BASELINE config 3: Tiramisu (FC-DenseNet) + MultiScalePrediction, 256x256 tiles, training step, bf16
     out["cfg3"] = {}
-    for name, filters, Bc in (("tiramisu_16_24_32", (16, 24, 32), 8), ("tiramisu_64_96_128_heavy", (64, 96, 128), 8)):
+    # (B = 8 and B = 32: BASELINE.md lists both batch sizes; at 8 tiles the light configuration's 107 launches are partly a batch artefact)
+    for name, filters, Bc in (("tiramisu_16_24_32", (16, 24, 32), 8), ("tiramisu_16_24_32_b32", (16, 24, 32), 32), ("tiramisu_64_96_128_heavy", (64, 96, 128), 8)):
         try:
             arch = Architecture(configs.cfg3_tiramisu(filters=filters, convs=4), device=device, dtype="bf16", seed=2)
             trainer = Trainer(arch, configs.bench_training(), Bc, 256, 256, world_size=1, use_graph=True)
@@ -487,21 +496,28 @@ def main():
             # what `roofline` is computed from, so that `frac` can be recomputed per layer without reading engine.py
             with open(args.dump_launches, "w") as fh:
                 json.dump([{"family": tag, "us": round(us, 2), **({k: v for k, v in info.items()} if info else {})} for tag, info, us in launches], fh, indent=0)
-        fam = "conv_igemm"
+        # the DOMINANT kernel family of the step = the one with the most time (round 6: with the 96-channel level's backward fused, the fused
+        # data + weight gradient launches -- conv_bwd_kernel, conv_bwd96_kernel -- take more of the step than the dd_conv_igemm launches, which
+        # were the dominant family through round 5; both stay in `mfma_families`)
+        fam = max((k for k in ("conv_igemm", "conv_bwd") if k in times and times[k][2] > 0), key=lambda k: times[k][1])
         n, ms, flops = times[fam]
         # the family's work is the sum over the launches that were timed; the engine's own records must say the same (round 4: they did not --
         # the layer-wise compose net recorded launches its fused replacement never runs)
-        rec_flops = sum(r["flops"] for r in trainer.program.g.conv_records)
-        assert abs(rec_flops - flops) <= 1e-9 * flops, ("conv_igemm records %.1f GFLOP != timed launches %.1f GFLOP" % (rec_flops / 1e9, flops / 1e9))
+        recs = trainer.program.g.conv_records if fam == "conv_igemm" else trainer.program.g.bwd_records
+        rec_flops = sum(r["flops"] for r in recs)
+        assert abs(rec_flops - flops) <= 1e-9 * flops, ("%s records %.1f GFLOP != timed launches %.1f GFLOP" % (fam, rec_flops / 1e9, flops / 1e9))
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
         # algorithmic HBM bytes of the same launches: every input and output element once, plus the output-shaped operands some launches
         # read (the ReLU mask of a dgrad, a residual, the gradient a launch accumulates into)
         esz = 4 if args.dtype == "f32" else 2
         alg_bytes = family_bytes(launches, fam, esz)
-        tr = measured_traffic(B, args.dtype)
-        roof = {"bound": "mfma", "kernel": "dd_conv_igemm launches <%s>: conv_igemm_ws_kernel, conv_rw_kernel, conv_rw8_kernel (forward + the data gradients the fused "
-                          "conv_bwd_kernel does not cover)" % args.dtype, "achieved": achieved, "peak": peak,
+        tr = measured_traffic(B, args.dtype, fam)
+        kname = {"conv_igemm": "dd_conv_igemm launches <%s>: conv_igemm_ws_kernel, conv_rw_kernel, conv_rw8_kernel (forward + the data gradients no fused "
+                               "backward kernel covers)" % args.dtype,
+                 "conv_bwd": "dd_conv3x3_bwd launches <%s>: conv_bwd_kernel (<= 64 output channels), conv_bwd96_kernel (65 - 96): data + weight + bias "
+                             "gradient of a 3x3 layer in one launch" % args.dtype}[fam]
+        roof = {"bound": "mfma", "kernel": kname, "family": fam, "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": tr["bytes_per_launch"] if tr else None,
                 "traffic_source": tr["source"] if tr else None, "algorithmic_bytes_per_launch": alg_bytes / n,
                 "launches_per_step": n, "avg_launch_us": 1e3 * ms / n,

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 #ifdef B96_EXP_STAMP      // (experiment build: cycles a wave spends in the tile-top wait / barrier, printed for two workgroups)
   long long stamp_vm = 0, stamp_bar = 0, stamp_n = 0;
   const long long stamp_t0 = __builtin_readcyclecounter();
+  const long long stamp_r0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: the ratio to the cycle counter is the shader clock
 #endif
   if (wave < 4) {
     // ================================================================== data-gradient role: wave = (input-channel tile cit, tile half)
@@ -331,11 +332,12 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
 #endif
     // db[co] = sum over pixels of dy: the centre-tap fragment (kernel row 1, column shift 1 = the unshifted tile) times an all-ones A operand -- one
     // more MFMA instead of 16 unpack / add instructions.  The 24 (row pair, output-channel tile) units of a tile are dealt round-robin to the
-    // ceil(cin / 16) active waves (input block, input-channel tile) that hold the same output channels, so no wave and no workgroup carries the bias alone
-    // (with the first block's waves summing it on the vector pipe those workgroups ran 8 % longer than the rest: cycle stamps).
+    // nblk workgroups of a tile sequence (their cit = 0 waves: ONE wave per workgroup and output channel, so that the order of the atomics on
+    // db is the workgroup order under DD_DETERMINISTIC=1), so no workgroup carries the bias alone (with the first block's waves summing it on
+    // the vector pipe those workgroups ran 8 % longer than the rest: cycle stamps).
     unsigned bias_mask = 0;
-    if (a.db != nullptr)
-      for (int u = 0; u < 24; ++u) bias_mask |= (unsigned)((u % ((a.cin + 15) >> 4)) == cb * 2 + cit) << u;      // (active waves: ids 0 .. ceil(cin / 16) - 1)
+    if (a.db != nullptr && cit == 0)
+      for (int u = 0; u < 24; ++u) bias_mask |= (unsigned)((u % a.nblk) == cb) << u;
     const unsigned one2 = sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? 0x3F803F80u : 0x3C003C00u;
     uint4 ones = {one2, one2, one2, one2};
     // (opaque: a known constant is re-materialised by a v_mov right in front of the in-place MFMA that reads it -- the VALU-write -> MFMA-read
@@ -450,8 +452,8 @@ __global__ __launch_bounds__(512) void conv_bwd96_kernel(const Bw96P a) {
   }
 #ifdef B96_EXP_STAMP
   if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 100))
-    printf("block %d wave %d: tiles %lld total %lld clk, vmcnt wait %lld, barrier %lld\n", (int)blockIdx.x, wave, stamp_n,
-           (long long)__builtin_readcyclecounter() - stamp_t0, stamp_vm, stamp_bar);
+    printf("block %d wave %d: tiles %lld total %lld clk (%lld ticks of 10 ns), vmcnt wait %lld, barrier %lld\n", (int)blockIdx.x, wave, stamp_n,
+           (long long)__builtin_readcyclecounter() - stamp_t0, (long long)__builtin_amdgcn_s_memrealtime() - stamp_r0, stamp_vm, stamp_bar);
 #endif
   dd_det_end();
 }
