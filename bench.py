@@ -248,6 +248,14 @@ def extras(device, B, H, W):
                         "same_buffers": {"value": steps * 1080 * 1920 / dt_same / 1e6, "ms_per_frame": 1e3 * dt_same / steps,
                                          "note": "every frame in the same device tensors: the input-assembly table upload is skipped"},
                         "device_time_ms_per_frame": {k: round(v, 4) if isinstance(v, float) else v for k, v in detail.items()}}
+    try:        # the same frames with the tile size a user may pass (Prediction.py --tile_size, default 128): 256-pixel tiles recompute 1.26 x the
+        # frame's pixels in their halos instead of 1.65 x.  Reported beside the default, never as `value`.
+        dt256 = inference_frames(device, "f16", 256, 64, steps, 2, 7, buffer_sets=3)
+        out["inference"]["tile_size_256"] = {"value": steps * 1080 * 1920 / dt256 / 1e6, "unit": "MPix/s", "ms_per_frame": 1e3 * dt256 / steps,
+                                             "note": "--tile_size 256 --tile_overlap_size 14 (45 tiles); the headline uses the reference's defaults 128 / 14 (209 tiles)"}
+    except Exception as e:
+        out["inference"]["tile_size_256"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
     try:        # roofline of the inference frame: per-launch HIP events of the forward program of the 209-tile batch
         arch = Architecture(configs.cfg2_unet_kpcn(), device=device, dtype="f16", seed=2)
         pred = Predictor(arch, tile_size=128, tile_overlap_size=14, tiles_per_batch=256)

@@ -110,7 +110,10 @@ int dd_conv_wgrad(const dd_wgrad_args* a, dd_stream stream);
 
 /* ---- fused backward of a 3x3 SAME conv2d (stride 1): the data gradient (Conv2DBackpropInput + the ReluGrad of the layer's input) AND the
  * weight / bias gradients (Conv2DBackpropFilter, BiasAddGrad) that TensorFlow's autodiff emits for tf.layers.conv2d (Training.py:701-702 over
- * UNet.py:38-48), from ONE pass over dy and x (dd_conv_igemm + dd_conv_wgrad fetch each of them twice).  bf16 / f16 storage, cout <= 64.
+ * UNet.py:38-48), from ONE pass over dy and x (dd_conv_igemm + dd_conv_wgrad fetch each of them twice).  bf16 / f16 storage.  With a data
+ * gradient: cout <= 64 in one launch (64 input channels per workgroup column), 65 <= cout <= 96 in one launch of the kernel that gives a
+ * workgroup a 32-channel third of the input against all output channels (round 6: the U-Net's 64 x 64 level, UNet.py:25-36); wider layers run
+ * as one launch per 64 output channels, the later ones accumulating into dx.
  *   dx[p][ci] = (use_mask ? x[p][ci] > 0 : 1) * sum_{t,co} wd[t][ci][co] * dy[p + off(t)][co]      (accumulate != 0: added to the existing dx)
  *   dw[t][ci][co] += sum_p x[p + off(t)][ci] * dy[p][co]     (TensorFlow kernel layout [3][3][cin][cout], fp32 atomics: zero it first)
  *   db[co] += sum_p dy[p][co]                                  (optional) */

@@ -242,7 +242,9 @@ def test_frame_input_state_of_a_shared_program_follows_the_frame_and_the_tile_pa
     finally:
         del os.environ["DD_FRAME_INPUT"]
     # tile path on the shared program, before and after a frame was read in place through it
-    tiles = {k: torch.stack([v[:T, :T], v[-T:, -T:]]) for k, v in make_frame(80, 80).items()}
+    assert pa.B == 2
+    Tp = pa.H                                                                # (the plan's tile: smaller than tile_size when the frame is)
+    tiles = {k: torch.stack([v[:Tp, :Tp], v[-Tp:, -Tp:]]) for k, v in make_frame(80, 80).items()}
     fresh = Architecture(aj, device="cuda", dtype="f32", seed=4)
     want = fresh.predict(tiles)[0][key].clone()
     pred.predict_frame(fb)

@@ -35,7 +35,8 @@ import glob
 for pth in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "parity_errors*.txt"))):
     shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag.split("_")[0], os.path.basename(pth))))
 for name in ("rw_loop_ubench.txt", "lds_probe.txt", "sq_table.txt", "wgrad_only_knockouts.txt", "deterministic.txt", "example_profile.txt", "ab_round5.txt",
-             "cfg3_light_launches.txt", "cfg3_heavy_launches.txt", "sq_table_cfg3_heavy.txt", "sq_table_cfg3_light.txt", "ks_shape_bench.txt"):
+             "cfg3_light_launches.txt", "cfg3_heavy_launches.txt", "sq_table_cfg3_heavy.txt", "sq_table_cfg3_light.txt", "ks_shape_bench.txt",
+             "ab_round6.txt", "b96_knockouts.txt", "b96_hbm.txt", "gate_diag.txt", "smoke.txt"):
     pth = os.path.join(src, name)
     if os.path.exists(pth):
         shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag, name)))
