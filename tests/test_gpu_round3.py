@@ -53,7 +53,7 @@ def _compare(what, dtype, aj, tj, B, H, W, fwd_gate, loss_gate, grad_median_gate
         63 - 126 % of its norm under storage rounding, its 24 -> 1 biases by 45x) and the emulation is ONE sample of that rounding noise: a second
         half-precision evaluation with a different fp32 summation order lands anywhere within the same distance.  What can be certified is that
         the device is AS GOOD an approximation of the true gradient as "round once where the tensor is stored" predicts:
-        |g_device - g_plain| <= 1.15 |g_emulated - g_plain| + 0.02 |g_plain|.  Measured (tools/gate_diag.py, profiles/r06_gate_diag.txt): the device
+        |g_device - g_plain| <= 1.15 |g_emulated - g_plain| + 0.02 |g_plain|.  Measured (tools/gate_diag.py, profiles/r06_a_gate_diag.txt): the device
         sits at 0.41 - 0.50 of the emulation's distance on every such tensor, fused compose kernels and layer-wise path alike (what VERDICT r5
         saw drifting, 0.447 -> 0.535 on reused_compose_scales/conv2d_5/kernel, was this noise measured against a gate of the wrong kind).
     The streaming compose backward's own gradients are gated without any conditioning, op by op, in
@@ -129,7 +129,7 @@ def test_cfg2_full_size_half_precision_against_the_storage_emulating_oracle(dtyp
     _compare("cfg-2 128x128 B=2", dtype, aj, tj, 2, 128, 128, *FULL_SIZE_GATES[dtype])
 
 
-SMALL_GATES = {"bf16": (1.5e-2, 1e-3, 0.1, 0.22), "f16": (4e-3, 2e-4, 0.1, 0.22)}      # gradient max: measured <= 0.109 over all cases (profiles/r06_*_parity_errors.txt)
+SMALL_GATES = {"bf16": (1.5e-2, 1e-3, 0.1, 0.22), "f16": (4e-3, 2e-4, 0.1, 0.22)}      # gradient max: measured <= 0.109 over all cases (profiles/r06_parity_errors.txt)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
