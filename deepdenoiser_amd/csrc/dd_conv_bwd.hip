@@ -27,6 +27,9 @@
 #ifndef CBW_DF_RING
 #define CBW_DF_RING 2      // the weight-gradient role's ring of dy fragments (2: one step ahead)
 #endif
+#ifndef CBW_REUSE
+#define CBW_REUSE 1        // the weight-gradient role keeps the three row-pair-aligned dy fragments of kernel row 2 for the next row pair's kernel row 0
+#endif
 #ifndef BW_DMA_SPAN
 #define BW_DMA_SPAN 8      // eighths of a tile's fragment steps over which the data-gradient waves issue the next tile's DMA pieces
 #endif
@@ -327,8 +330,17 @@ __device__ __forceinline__ void conv_bwd_body(const BwdP& a, char* smem, int blo
       if (!active) continue;
       // 72 steps = 8 pixel-row pairs x 9 taps, 4 MFMAs each; the dy fragment of step n+1 and (during taps 4..7) the x fragments of the next
       // row pair are requested before the MFMAs of step n.  sched_barriers keep hipcc from hoisting a whole row pair's 26 reads (52 registers).
+      // (round 6) The dy fragment of tap (kernel row 0, column shift tx) of row pair s covers the haloed rows (2s, 2s + 1) -- the SAME fragment as tap
+      // (kernel row 2, tx) of row pair s - 1: it is kept in registers (3 fragments) instead of read again: 10 transposing read pairs per 36 MFMAs
+      // instead of 13 on the role whose bound is that instruction's return path.
       constexpr int DFR = CBW_DF_RING, DFA = DFR - 1;      // dy fragments requested DFA steps ahead
       uint4 xf[2][4], df[DFR];
+#if CBW_REUSE
+      uint4 keep[3];
+#define CBW_NEEDS_READ(st) (!((st) >= 9 && (st) % 9 < 3))
+#else
+#define CBW_NEEDS_READ(st) true
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) xf[0][i] = x_frag(0, i);
 #pragma unroll
@@ -338,19 +350,25 @@ __device__ __forceinline__ void conv_bwd_body(const BwdP& a, char* smem, int blo
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int step = s * 9 + t;
-        if (step + DFA < 72) df[(step + DFA) % DFR] = dy_frag(step + DFA);
+        if (step + DFA < 72 && CBW_NEEDS_READ(step + DFA)) df[(step + DFA) % DFR] = dy_frag(step + DFA);
 #ifdef CBW_EXP_HALF_X
         if (s + 1 < 8 && t >= 4 && t < 6) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
 #else
         if (s + 1 < 8 && t >= 4 && t < 8) xf[(s + 1) & 1][t - 4] = x_frag(s + 1, t - 4);
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#if CBW_REUSE
+        const uint4 cur = (s > 0 && t < 3) ? keep[t] : df[step % DFR];
+        if (t >= 6) keep[t - 6] = cur;
+#else
+        const uint4 cur = df[step % DFR];
+#endif
 #ifdef CBW_EXP_HALF_MMA
 #pragma unroll
-        for (int i = 0; i < 2; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], df[step % DFR]);
+        for (int i = 0; i < 2; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], cur);
 #else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], df[step % DFR]);
+        for (int i = 0; i < 4; ++i) bw_mma_inplace<T>(acc[t][i], xf[s & 1][i], cur);
 #endif
         if (t == 4 && bias_wave) {      // centre tap = the unshifted dy tile: 8 pixels of channel wr*16 + li per lane
           float f[8];
