@@ -99,3 +99,39 @@ def test_fixture_covers_the_reference_paths_it_claims():
     created = [l for l in log if l.endswith(" create")]
     reused = [l for l in log if l.endswith(" reuse")]
     assert len(created) == len(META["example_single_embedding"]["variables"]) and len(reused) > 10 * len(created)
+
+
+def test_stub_variable_scopes_follow_the_tf1_rules_the_wiring_relies_on():
+    """tests/golden/tf_stub.py alone (no reference needed): default layer names count per variable scope and restart when the scope is entered
+    again; reuse=False on an existing variable and reuse=True on a missing one raise as TensorFlow does; AUTO_REUSE creates once."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("dd_tf_stub_selftest", os.path.join(HERE, "golden", "tf_stub.py"))
+    tf = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = tf
+    spec.loader.exec_module(tf)
+    tf.STORE.reset(3)
+    x = torch.ones(1, 4, 4, 3, dtype=torch.float64)
+    with tf.variable_scope("core", reuse=False):
+        y = tf.layers.conv2d(x, 5, (3, 3), padding="same", activation=tf.nn.relu)
+        y = tf.layers.conv2d(y, 5, (1, 1), padding="same")
+        y = tf.layers.conv2d_transpose(y, 2, (2, 2), strides=(2, 2), padding="same")
+    assert list(tf.STORE.vars) == ["core/conv2d/kernel", "core/conv2d/bias", "core/conv2d_1/kernel", "core/conv2d_1/bias",
+                                   "core/conv2d_transpose/kernel", "core/conv2d_transpose/bias"]
+    assert tuple(tf.STORE.vars["core/conv2d_transpose/kernel"].shape) == (2, 2, 2, 5) and tuple(y.shape) == (1, 8, 8, 2)
+    with tf.variable_scope("core", reuse=True):                      # second pass: the counters restart, the same variables bind in order
+        tf.layers.conv2d(x, 5, (3, 3), padding="same")
+        tf.layers.conv2d(torch.ones(1, 4, 4, 5, dtype=torch.float64), 5, (1, 1), padding="same")
+        with pytest.raises(ValueError):
+            tf.layers.conv2d(x, 5, (3, 3), padding="same")          # would be core/conv2d_2: does not exist
+    assert len(tf.STORE.vars) == 6
+    with tf.variable_scope("core", reuse=False):
+        with pytest.raises(ValueError):
+            tf.layers.conv2d(x, 5, (3, 3), padding="same")          # core/conv2d exists: TensorFlow refuses without reuse
+    for _ in range(2):
+        with tf.variable_scope("embedding", reuse=tf.AUTO_REUSE):
+            m = tf.get_variable("feature_flags_embedding_matrix", [4, 2], trainable=True)
+    assert "embedding/feature_flags_embedding_matrix" in tf.STORE.vars and tuple(m.shape) == (4, 2)
+    # symmetric padding mirrors INCLUDING the edge sample (SURVEY A.7)
+    p = tf.pad(torch.arange(9, dtype=torch.float64).reshape(1, 3, 3, 1), [[0, 0], [1, 1], [1, 1], [0, 0]], "symmetric")
+    assert p[0, :, :, 0].tolist() == [[0, 0, 1, 2, 2], [0, 0, 1, 2, 2], [3, 3, 4, 5, 5], [6, 6, 7, 8, 8], [6, 6, 7, 8, 8]]
